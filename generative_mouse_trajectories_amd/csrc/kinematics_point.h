@@ -1,0 +1,189 @@
+// Per-point bodies of the kinematics kernels (RecurrentGAN.py:315-389, "mode A").
+// Shared by kinematics.hip (device) and by the host-side simulation build that the CPU
+// tests use to check the arithmetic without a GPU (tests/hostsim).
+#pragma once
+#include <math.h>
+#ifndef GMT_HD
+#  ifdef __HIPCC__
+#    define GMT_HD __host__ __device__ __forceinline__
+#  else
+#    define GMT_HD static inline
+#  endif
+#endif
+
+namespace gmt_kin {
+
+struct F2 { float x, y; };
+
+struct Pt {            // quantities of point t that need points t and t-1 only
+    float dx, dy, td, disp, vel, vx, vy;
+};
+
+GMT_HD Pt make_pt(float x, float y, float xp, float yp, float d, bool has_prev, float eps) {
+    Pt p;
+    p.dx = has_prev ? x - xp : 0.0f;                               // RG.py:335-338
+    p.dy = has_prev ? y - yp : 0.0f;
+    p.td = d + eps;
+    p.disp = sqrtf(p.dx * p.dx + p.dy * p.dy + eps);               // RG.py:341
+    p.vel = p.disp / p.td;                                         // RG.py:342
+    p.vx = p.dx / p.td;                                            // RG.py:345-346
+    p.vy = p.dy / p.td;
+    return p;
+}
+
+GMT_HD void kin_fwd_point(long long idx, const float* pos, const float* dts, float* feat, int L, int B, float eps)
+{
+    const int t = (int)(idx / B);
+    // window t-3 .. t (clamped loads; the has_prev flags zero what does not exist)
+    float x[4], y[4], d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int tt = t - 3 + k;
+        long long j = idx - (long long)(3 - k) * B;
+        if (tt < 0) j = idx - (long long)t * B;
+        const F2 p = reinterpret_cast<const F2*>(pos)[j];
+        x[k] = p.x; y[k] = p.y; d[k] = dts[j];
+    }
+    Pt p0 = make_pt(x[3], y[3], x[2], y[2], d[3], t >= 1, eps);       // t
+    Pt p1 = make_pt(x[2], y[2], x[1], y[1], d[2], t >= 2, eps);       // t-1
+    Pt p2 = make_pt(x[1], y[1], x[0], y[0], d[1], t >= 3, eps);       // t-2
+    float acc = 0.f, accp = 0.f, jerk = 0.f, ax = 0.f, ay = 0.f;
+    if (t >= 1) {
+        float m = (d[3] + d[2]) * 0.5f + eps;                         // RG.py:351
+        acc = (p0.vel - p1.vel) / m;                                  // RG.py:352
+        ax = (p0.vx - p1.vx) / m;                                     // RG.py:363-364
+        ay = (p0.vy - p1.vy) / m;
+        if (t >= 2) {
+            float mp = (d[2] + d[1]) * 0.5f + eps;
+            accp = (p1.vel - p2.vel) / mp;
+            jerk = (acc - accp) / (m + eps);                          // RG.py:356-357
+        }
+    }
+    float u = p0.vx * p0.vx + p0.vy * p0.vy + eps;
+    float curv = fabsf(p0.vx * ay - p0.vy * ax) / (u * sqrtf(u));     // RG.py:366-368
+    float* o = feat + idx * 9;
+    o[0] = x[3]; o[1] = y[3]; o[2] = p0.dx; o[3] = p0.dy; o[4] = d[3];
+    o[5] = fminf(fmaxf(p0.vel, 0.f), 100.f);                          // RG.py:371-374
+    o[6] = fminf(fmaxf(acc, -1000.f), 1000.f);
+    o[7] = fminf(fmaxf(jerk, -10000.f), 10000.f);
+    o[8] = fminf(fmaxf(curv, 0.f), 100.f);
+}
+
+// Backward for point (s, b): gathers d(loss)/d(pos_s), d(loss)/d(dts_s) from the feature
+// gradients of points s .. s+3, recomputing the forward window s-3 .. s+3.
+GMT_HD void kin_bwd_point(long long idx, const float* pos, const float* dts, const float* gfeat,
+                          float* gpos, float* gdts, int L, int B, float eps)
+{
+    const int s = (int)(idx / B);
+    // points s-3 .. s+3 -> local index k = tt - (s-3)
+    float x[7], y[7], d[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        int tt = s - 3 + k;
+        tt = tt < 0 ? 0 : (tt > L - 1 ? L - 1 : tt);
+        long long j = idx + (long long)(tt - s) * B;
+        const F2 p = reinterpret_cast<const F2*>(pos)[j];
+        x[k] = p.x; y[k] = p.y; d[k] = dts[j];
+    }
+    // Pt for tt = s-2 .. s+3 -> P[k], tt = s-2+k
+    Pt P[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int tt = s - 2 + k;
+        P[k] = make_pt(x[k + 1], y[k + 1], x[k], y[k], d[k + 1], tt >= 1, eps);
+    }
+    // m, acc, ax, ay for tt = s-1 .. s+3 -> index k, tt = s-1+k  (valid when 1 <= tt <= L-1)
+    float m[5], acc[5], axv[5], ayv[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        int tt = s - 1 + k;
+        bool ok = (tt >= 1) && (tt <= L - 1);
+        m[k] = (d[k + 2] + d[k + 1]) * 0.5f + eps;
+        acc[k] = ok ? (P[k + 1].vel - P[k].vel) / m[k] : 0.f;
+        axv[k] = ok ? (P[k + 1].vx - P[k].vx) / m[k] : 0.f;
+        ayv[k] = ok ? (P[k + 1].vy - P[k].vy) / m[k] : 0.f;
+    }
+    // feature gradients of tt = s .. s+3 (zero outside the sequence)
+    float g[4][9];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int tt = s + k;
+        bool ok = tt <= L - 1;
+        const float* gp = gfeat + (idx + (long long)(ok ? k : 0) * B) * 9;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) g[k][c] = ok ? gp[c] : 0.f;
+    }
+    // jerk adjoint Jb[k], tt = s+k (k = 0..3); jerk value jv[k]
+    float Jb[4], jv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int tt = s + k;
+        bool ok = (tt >= 2) && (tt <= L - 1);
+        float j = ok ? (acc[k + 1] - acc[k]) / (m[k + 1] + eps) : 0.f;
+        jv[k] = j;
+        Jb[k] = (ok && j >= -10000.f && j <= 10000.f) ? g[k][7] : 0.f;
+    }
+    // acc adjoint Ab[k], tt = s+k (k = 0..2)
+    float Ab[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int tt = s + k;
+        bool ok = (tt >= 1) && (tt <= L - 1);
+        float a = acc[k + 1];
+        float v = (a >= -1000.f && a <= 1000.f) ? g[k][6] : 0.f;
+        v += Jb[k] / (m[k + 1] + eps);
+        v -= Jb[k + 1] / (m[k + 2] + eps);      // Jb is zero when tt+1 is outside
+        Ab[k] = ok ? v : 0.f;
+    }
+    // curvature adjoints at tt = s+k (k = 0..2): qb, ub, axb, ayb
+    float qb[3], ub[3], axb[3], ayb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int tt = s + k;
+        bool ok = tt <= L - 1;
+        const Pt& p = P[k + 2];
+        float ax = axv[k + 1], ay = ayv[k + 1];
+        float q = p.vx * ay - p.vy * ax;
+        float u = p.vx * p.vx + p.vy * p.vy + eps;
+        float su = sqrtf(u);
+        float s3 = u * su;
+        float cross = fabsf(q);
+        float curv = cross / s3;
+        float Cb = (ok && curv >= 0.f && curv <= 100.f) ? g[k][8] : 0.f;
+        float sgn = q > 0.f ? 1.f : (q < 0.f ? -1.f : 0.f);
+        qb[k] = Cb * sgn / s3;
+        ub[k] = -Cb * curv * 1.5f / u;          // d(cross/u^1.5)/du = -1.5 * curv / u
+        bool okA = ok && tt >= 1;
+        axb[k] = okA ? -qb[k] * p.vy : 0.f;
+        ayb[k] = okA ? qb[k] * p.vx : 0.f;
+    }
+    // per tt = s+k (k = 0..1): Vb, VXb, VYb, mb, then dxb, dyb, tdb
+    float dxb[2], dyb[2], mb[2], tdb0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        int tt = s + k;
+        bool ok = tt <= L - 1;
+        const Pt& p = P[k + 2];
+        float ax = axv[k + 1], ay = ayv[k + 1];
+        float Vb = (p.vel >= 0.f && p.vel <= 100.f) ? g[k][5] : 0.f;
+        Vb += Ab[k] / m[k + 1];                  // Ab is zero for tt < 1
+        Vb -= Ab[k + 1] / m[k + 2];              // zero when tt+1 outside
+        float VXb = qb[k] * ay + 2.f * ub[k] * p.vx + axb[k] / m[k + 1] - axb[k + 1] / m[k + 2];
+        float VYb = -qb[k] * ax + 2.f * ub[k] * p.vy + ayb[k] / m[k + 1] - ayb[k + 1] / m[k + 2];
+        float dispb = Vb / p.td;
+        float tdb = -Vb * p.vel / p.td - VXb * p.vx / p.td - VYb * p.vy / p.td;
+        dxb[k] = ok ? (g[k][2] + VXb / p.td + dispb * p.dx / p.disp) : 0.f;
+        dyb[k] = ok ? (g[k][3] + VYb / p.td + dispb * p.dy / p.disp) : 0.f;
+        bool okM = ok && tt >= 1;
+        mb[k] = okM ? (-Ab[k] * acc[k + 1] / m[k + 1] - Jb[k] * jv[k] / (m[k + 1] + eps)
+                       - axb[k] * ax / m[k + 1] - ayb[k] * ay / m[k + 1]) : 0.f;
+        if (k == 0) tdb0 = tdb;
+    }
+    float gx = g[0][0] + (s >= 1 ? dxb[0] : 0.f) - dxb[1];
+    float gy = g[0][1] + (s >= 1 ? dyb[0] : 0.f) - dyb[1];
+    float gd = g[0][4] + tdb0 + 0.5f * (mb[0] + mb[1]);
+    gpos[idx * 2] = gx; gpos[idx * 2 + 1] = gy;
+    gdts[idx] = gd;
+}
+
+}  // namespace gmt_kin
