@@ -1,0 +1,86 @@
+"""ctypes binding of libgmt_hip.so (include/gmt_hip.h).  The library is built in-tree by
+`_build.build()`; there is NO fallback: if it is missing or its ABI version differs, every
+entry point raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libgmt_hip.so')
+ABI_VERSION = 1
+_lib = None
+
+ERRORS = {-1: 'bad argument (null pointer / shape / alignment)', -2: 'unsupported configuration',
+          -3: 'HIP launch failed', -4: 'workspace too small'}
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_ll = ctypes.c_longlong
+c_f = ctypes.c_float
+c_d = ctypes.c_double
+
+_SIGS = {
+    'gmt_version': [],
+    'gmt_kinematics_fwd': [c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    'gmt_kinematics_bwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    'gmt_telemetry_kinematics_f64': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_d, c_d, c_p],
+    'gmt_telemetry_derived_f64': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_p],
+    'gmt_adam_step': [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_f, c_p],
+    'gmt_pack_weight': [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_p],
+    'gmt_lstm_layer_fwd': [c_p] * 10 + [c_i] * 5 + [c_p],
+    'gmt_lstm_layer_bwd': [c_p] * 8 + [c_i] * 4 + [c_p],
+}
+
+
+class GmtError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GmtError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(there is no non-HIP fallback)')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, sig in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = sig
+            fn.restype = c_i
+        if L.gmt_version() != ABI_VERSION:
+            raise GmtError(f'libgmt_hip.so ABI {L.gmt_version()} != expected {ABI_VERSION}: rebuild')
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGS.keys())
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise GmtError('non-contiguous tensor passed to a HIP kernel')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise GmtError(f'{name} failed: {ERRORS.get(rc, rc)}')
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GmtError('this path runs on the GPU only (hand-written HIP kernels, no CPU fallback); '
+                           f'got a tensor on {t.device}')

@@ -1,0 +1,407 @@
+// Persistent (whole-sequence) LSTM layer kernels for the discriminator's packed,
+// bidirectional LSTM - RecurrentGAN.py:720-727 called at RG.py:764-778, i.e.
+// torch.nn.LSTM over pack_padded_sequence(lengths, enforce_sorted=False).
+//
+// One launch runs one layer, both directions, all timesteps.  Workgroup = (direction,
+// tile of 32 trajectories); see lstm_tile.h for the wave/MFMA/LDS decomposition.
+// Packed-sequence semantics are a per-row length mask: a row's state advances at step t
+// only when t < len; the reverse direction walks t = L-1 .. 0 and therefore starts each
+// row at its own last valid step with zero state.  Outputs at padded steps are zero.
+//
+// Forward saves the activated gates (i,f,g,o), c and h of every step for the backward
+// sweep; backward overwrites the gate buffer in place with d(pre-activation), which the
+// host then contracts with x / h_prev for the weight gradients (one large GEMM each).
+#include "lstm_tile.h"
+
+namespace {
+
+// ------------------------------------------------------------------ weight packing
+__global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int k_valid,
+                            int n_waves, int n_gates, int gate_stride, long long sk, long long sn)
+{
+    const long long total = (long long)n_waves * (K / 8) * n_gates * 64 * 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3);
+        const int lane = (int)((i >> 2) & 63);
+        long long q = i >> 8;
+        const int g = (int)(q % n_gates); q /= n_gates;
+        const int s4 = (int)(q % (K / 8));
+        const int w = (int)(q / (K / 8));
+        const int k = 2 * (4 * s4 + e) + (lane >> 5);
+        const int n = g * gate_stride + 32 * w + (lane & 31);
+        dst[i] = (k < k_valid) ? src[(long long)k * sk + (long long)n * sn] : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------ forward
+// NW waves (H = 32 NW).  RES: recurrent weights resident in registers.  IX = I / H:
+//   IX = 0  the caller precomputed x W_ih^T + b into `pregates` (read from HBM);
+//   IX = 1,2 the input contraction runs inside the kernel, W_ih streamed from L2.
+// B must be a multiple of 32 (the host pads the batch), so there are no row guards.
+template <int NW, bool RES, int IX>
+__global__ __launch_bounds__(NW * 64, 1)
+void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pregates,
+                     const float* __restrict__ w_ih_pk, const float* __restrict__ w_hh_pk,
+                     const float* __restrict__ bias, const int* __restrict__ lengths,
+                     float* __restrict__ gates, float* __restrict__ c_all, float* __restrict__ h_all,
+                     float* __restrict__ h_final, int L, int B, int ndir, int n_tiles)
+{
+    constexpr int H = NW * 32;
+    constexpr int KS = H / 2;
+    constexpr int I = (IX > 0 ? IX : 1) * H;
+    constexpr int NT = NW * 64;
+    extern __shared__ float smem[];
+    float* hT = smem;                                  // [2][H][LDA]
+    float* xT = smem + 2 * H * GMT_LDA;                // [2][I][LDA] (IX > 0 only)
+    __shared__ int s_len[GMT_TM];
+    __shared__ int s_maxlen;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.x / n_tiles;
+    const int row0 = (blockIdx.x % n_tiles) * GMT_TM;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int col = wave * 32 + lo;                    // hidden unit of this lane
+
+    if (tid == 0) s_maxlen = 0;
+    __syncthreads();
+    if (tid < GMT_TM) {
+        int ln = lengths ? lengths[row0 + tid] : L;
+        ln = ln < 1 ? 1 : (ln > L ? L : ln);           // RG.py:766 clamp(min=1)
+        s_len[tid] = ln;
+        atomicMax(&s_maxlen, ln);
+    }
+    for (int i = tid; i < 2 * H * GMT_LDA; i += NT) hT[i] = 0.0f;
+    __syncthreads();
+    const int tmax = s_maxlen;                         // steps [tmax, L) are padding for the whole tile
+
+    const float4* whh = reinterpret_cast<const float4*>(w_hh_pk) + ((size_t)dir * NW + wave) * (H / 8) * 4 * 64;
+    const float4* wih = IX > 0 ? reinterpret_cast<const float4*>(w_ih_pk) + ((size_t)dir * NW + wave) * (I / 8) * 4 * 64
+                               : nullptr;
+    float wr[4][RES ? KS : 1];
+    if constexpr (RES) gmt_load_resident<4, KS>(wr, whh, lane);
+
+    float bz[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (IX > 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bz[g] = bias[(size_t)dir * 4 * H + g * H + col];
+    }
+
+    float c[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+
+    // x tile staging: the 32 x I tile of step t is one contiguous run of x.  global ->
+    // registers early in the step, registers -> LDS (transposed) at its end, so the HBM
+    // latency hides under the MFMAs (T14 split).
+    constexpr int XQ = I / 4;                          // float4 per row
+    constexpr int XS = (GMT_TM * XQ) / NT;             // float4 per thread (= 4 * IX)
+    float4 xs[IX > 0 ? XS : 1];
+    auto x_load = [&](int t) {
+        const float4* src = reinterpret_cast<const float4*>(x + ((size_t)t * B + row0) * I);
+#pragma unroll
+        for (int j = 0; j < XS; ++j) xs[j] = src[tid + j * NT];
+    };
+    auto x_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < XS; ++j) {
+            const int it = tid + j * NT;
+            const int rr = it / XQ, c4 = it % XQ;
+            float* d = xT + ((size_t)buf * I + 4 * c4) * GMT_LDA + rr;
+            d[0] = xs[j].x; d[GMT_LDA] = xs[j].y; d[2 * GMT_LDA] = xs[j].z; d[3 * GMT_LDA] = xs[j].w;
+        }
+    };
+
+    int cur = 0;
+    if constexpr (IX > 0) {
+        if (tmax > 0) { x_load(dir ? tmax - 1 : 0); x_store(0); }
+        __syncthreads();
+    }
+
+    const size_t lane_row = (size_t)row0 + 4 * hi;     // first row of this lane's accumulator rows
+    for (int step = 0; step < tmax; ++step) {
+        const int t = dir ? (tmax - 1 - step) : step;
+        const size_t rs = ((size_t)dir * L + t) * B + lane_row;
+        f32x16 acc[4];
+        if constexpr (IX > 0) {
+            if (step + 1 < tmax) x_load(dir ? t - 1 : t + 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = bz[g];
+            gmt_mma_stream<4>(acc, xT + (size_t)cur * I * GMT_LDA, wih, I, lane);
+        } else {
+            const float* pp = pregates + rs * (4 * H) + col;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[g][r] = pp[(size_t)((r & 3) + 8 * (r >> 2)) * (4 * H) + g * H];
+        }
+        if constexpr (RES) gmt_mma_resident<4, KS>(acc, hT + (size_t)cur * H * GMT_LDA, wr, lane);
+        else gmt_mma_stream<4>(acc, hT + (size_t)cur * H * GMT_LDA, whh, H, lane);
+
+        const float* ho = hT + (size_t)cur * H * GMT_LDA + col * GMT_LDA + 4 * hi;
+        float* hn = hT + (size_t)(cur ^ 1) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
+        float* gp = gates ? gates + rs * (4 * H) + col : nullptr;
+        float* cp = c_all ? c_all + rs * H + col : nullptr;
+        float* hp = h_all ? h_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col : nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2);     // row within the tile, minus 4*hi
+            const bool act = t < s_len[mr + 4 * hi];
+            const float ig = gmt_sigmoid(acc[0][r]);
+            const float fg = gmt_sigmoid(acc[1][r]);
+            const float gg = gmt_tanh(acc[2][r]);
+            const float og = gmt_sigmoid(acc[3][r]);
+            const float cn = fg * c[r] + ig * gg;
+            const float hv = og * gmt_tanh(cn);
+            c[r] = act ? cn : c[r];
+            hn[mr] = act ? hv : ho[mr];
+            if (gp) {
+                float* q = gp + (size_t)mr * (4 * H);
+                q[0] = act ? ig : 0.f; q[H] = act ? fg : 0.f; q[2 * H] = act ? gg : 0.f; q[3 * H] = act ? og : 0.f;
+            }
+            if (cp) cp[(size_t)mr * H] = act ? cn : 0.f;
+            if (hp) hp[(size_t)mr * (ndir * H)] = act ? hv : 0.f;
+        }
+        if constexpr (IX > 0) {
+            if (step + 1 < tmax) x_store(cur ^ 1);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // padded tail of the whole tile: outputs are zero (pad_packed_sequence)
+    if (h_all) {
+        for (int t = tmax; t < L; ++t) {
+            float* hp = h_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hp[(size_t)((r & 3) + 8 * (r >> 2)) * (ndir * H)] = 0.f;
+        }
+    }
+    if (h_final) {
+        const float* hl = hT + (size_t)cur * H * GMT_LDA + col * GMT_LDA + 4 * hi;
+        float* hf = h_final + lane_row * (ndir * H) + dir * H + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2);
+            hf[(size_t)mr * (ndir * H)] = hl[mr];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward
+// Reverse sweep of one layer.  State: dh, dc of the wave's 32 units (accumulator layout).
+// Per step: d(pre-activation) from the saved gates -> written over the gate buffer and to
+// LDS (transposed) -> dh_prev = da W_hh as an MFMA contraction over K = 4H with W_hh
+// resident in registers (or streamed).
+template <int NW, bool RES>
+__global__ __launch_bounds__(NW * 64, 1)
+void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, const float* __restrict__ c_all,
+                     const float* __restrict__ w_hh_pkT, const int* __restrict__ lengths,
+                     const float* __restrict__ dh_all /* [L][B][ndir*H] or null */,
+                     const float* __restrict__ dh_final /* [B][ndir*H] or null */,
+                     const float* __restrict__ dgates_extra /* [ndir][L][B][4H] or null: extra adjoint of the activated gates */,
+                     const float* __restrict__ dc_extra /* [ndir][L][B][H] or null */,
+                     int L, int B, int ndir, int n_tiles)
+{
+    constexpr int H = NW * 32;
+    constexpr int KS = 2 * H;                          // k-steps over K = 4H
+    constexpr int NT = NW * 64;
+    extern __shared__ float smem[];
+    float* daT = smem;                                 // [4H][LDA]
+    __shared__ int s_len[GMT_TM];
+    __shared__ int s_maxlen;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.x / n_tiles;
+    const int row0 = (blockIdx.x % n_tiles) * GMT_TM;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int col = wave * 32 + lo;
+
+    if (tid == 0) s_maxlen = 0;
+    __syncthreads();
+    if (tid < GMT_TM) {
+        int ln = lengths ? lengths[row0 + tid] : L;
+        ln = ln < 1 ? 1 : (ln > L ? L : ln);
+        s_len[tid] = ln;
+        atomicMax(&s_maxlen, ln);
+    }
+    __syncthreads();
+    const int tmax = s_maxlen;
+
+    const float4* wT = reinterpret_cast<const float4*>(w_hh_pkT) + ((size_t)dir * NW + wave) * (4 * H / 8) * 64;
+    float wr[1][RES ? KS : 1];
+    if constexpr (RES) gmt_load_resident<1, KS>(wr, wT, lane);
+
+    const size_t lane_row = (size_t)row0 + 4 * hi;
+    float dh[16], dc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mr = (r & 3) + 8 * (r >> 2);
+        dh[r] = dh_final ? dh_final[(lane_row + mr) * (ndir * H) + dir * H + col] : 0.f;
+        dc[r] = 0.f;
+    }
+
+    // forward visited t in order (dir 0: 0..tmax-1, dir 1: tmax-1..0); walk it backwards
+    for (int step = tmax - 1; step >= 0; --step) {
+        const int t = dir ? (tmax - 1 - step) : step;
+        const int tp = dir ? t + 1 : t - 1;            // the step the forward pass visited before t
+        const size_t rs = ((size_t)dir * L + t) * B + lane_row;
+        float* gp = gates + rs * (4 * H) + col;
+        const float* cn_p = c_all + rs * H + col;
+        const float* cp_p = c_all + (((size_t)dir * L + (tp < 0 ? 0 : tp)) * B + lane_row) * H + col;
+        const float* dy_p = dh_all ? dh_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col : nullptr;
+        const float* ge_p = dgates_extra ? dgates_extra + rs * (4 * H) + col : nullptr;
+        const float* ce_p = dc_extra ? dc_extra + rs * H + col : nullptr;
+        f32x16 acc[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2);
+            const int m = mr + 4 * hi;
+            const int ln = s_len[m];
+            const bool act = t < ln;
+            float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
+            float* q = gp + (size_t)mr * (4 * H);
+            if (act) {
+                const float ig = q[0], fg = q[H], gg = q[2 * H], og = q[3 * H];
+                const float cn = cn_p[(size_t)mr * H];
+                const bool has_prev = dir ? (tp < ln) : (tp >= 0);
+                const float cp = has_prev ? cp_p[(size_t)mr * H] : 0.f;
+                float dht = dh[r];
+                if (dy_p) dht += dy_p[(size_t)mr * (ndir * H)];
+                const float tc = gmt_tanh(cn);
+                float dog = dht * tc;
+                float dct = dc[r] + dht * og * (1.f - tc * tc);
+                if (ce_p) dct += ce_p[(size_t)mr * H];
+                float dig = dct * gg, dgg = dct * ig, dfg = dct * cp;
+                if (ge_p) {
+                    const float* ep = ge_p + (size_t)mr * (4 * H);
+                    dig += ep[0]; dfg += ep[H]; dgg += ep[2 * H]; dog += ep[3 * H];
+                }
+                dc[r] = dct * fg;
+                dai = dig * ig * (1.f - ig);
+                daf = dfg * fg * (1.f - fg);
+                dag = dgg * (1.f - gg * gg);
+                dao = dog * og * (1.f - og);
+                acc[0][r] = 0.f;                       // dh_prev = da W_hh only
+            } else {
+                acc[0][r] = dh[r];                     // frozen row: state passes through
+            }
+            // d(pre-activation) replaces the gates (zero at padded steps: the weight-gradient GEMM reads it)
+            q[0] = dai; q[H] = daf; q[2 * H] = dag; q[3 * H] = dao;
+            daT[(0 * H + col) * GMT_LDA + m] = dai;
+            daT[(1 * H + col) * GMT_LDA + m] = daf;
+            daT[(2 * H + col) * GMT_LDA + m] = dag;
+            daT[(3 * H + col) * GMT_LDA + m] = dao;
+        }
+        __syncthreads();
+        if constexpr (RES) gmt_mma_resident<1, KS>(acc, daT, wr, lane);
+        else gmt_mma_stream<1>(acc, daT, wT, 4 * H, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = acc[0][r];
+        __syncthreads();
+    }
+    // steps [tmax, L) of the tile are padding: zero their d(pre-activation)
+    for (int t = tmax; t < L; ++t) {
+        float* gp = gates + (((size_t)dir * L + t) * B + lane_row) * (4 * H) + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* q = gp + (size_t)((r & 3) + 8 * (r >> 2)) * (4 * H);
+            q[0] = 0.f; q[H] = 0.f; q[2 * H] = 0.f; q[3 * H] = 0.f;
+        }
+    }
+}
+
+template <int NW>
+int launch_fwd(const float* x, const float* pregates, const float* w_ih_pk, const float* w_hh_pk, const float* bias,
+               const int* lengths, float* gates, float* c_all, float* h_all, float* h_final,
+               int L, int B, int I, int ndir, hipStream_t stream)
+{
+    constexpr int H = NW * 32;
+    constexpr bool RES = (NW <= 4);
+    const int n_tiles = B / GMT_TM;
+    const dim3 grid(n_tiles * ndir), block(NW * 64);
+#define GMT_GO(IXV, LDSF)                                                                                         \
+    {                                                                                                             \
+        const size_t lds = (size_t)(LDSF) * GMT_LDA * sizeof(float);                                              \
+        if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;                                                   \
+        auto k = lstm_fwd_kernel<NW, RES, IXV>;                                                                   \
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return GMT_ERR_HIP;                                                                                   \
+        hipLaunchKernelGGL(k, grid, block, lds, stream, x, pregates, w_ih_pk, w_hh_pk, bias, lengths, gates,      \
+                           c_all, h_all, h_final, L, B, ndir, n_tiles);                                           \
+    }
+    if (!x) GMT_GO(0, 2 * H)
+    else if (I == H) GMT_GO(1, 2 * H + 2 * H)
+    else if (I == 2 * H) GMT_GO(2, 2 * H + 4 * H)
+    else return GMT_ERR_UNSUPPORTED;
+#undef GMT_GO
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+template <int NW>
+int launch_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths, const float* dh_all,
+               const float* dh_final, const float* dgates_extra, const float* dc_extra,
+               int L, int B, int ndir, hipStream_t stream)
+{
+    constexpr int H = NW * 32;
+    constexpr bool RES = (NW <= 4);
+    const int n_tiles = B / GMT_TM;
+    const size_t lds = (size_t)(4 * H) * GMT_LDA * sizeof(float);
+    if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;
+    auto k = lstm_bwd_kernel<NW, RES>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return GMT_ERR_HIP;
+    hipLaunchKernelGGL(k, dim3(n_tiles * ndir), dim3(NW * 64), lds, stream, gates, c_all, w_hh_pkT, lengths,
+                       dh_all, dh_final, dgates_extra, dc_extra, L, B, ndir, n_tiles);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+}  // namespace
+
+extern "C" int gmt_pack_weight(const float* src, float* dst, int K, int k_valid, int n_waves, int n_gates,
+                               int gate_stride, long long stride_k, long long stride_n, hipStream_t stream)
+{
+    GMT_CHECK_ARG(src && dst && K >= 8 && (K % 8) == 0 && k_valid >= 1 && k_valid <= K && n_waves >= 1 && n_gates >= 1);
+    const long long total = (long long)n_waves * (K / 8) * n_gates * 256;
+    hipLaunchKernelGGL(pack_kernel, dim3(gmt_grid_1d(total, 256)), dim3(256), 0, stream, src, dst, K, k_valid,
+                       n_waves, n_gates, gate_stride, stride_k, stride_n);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+extern "C" int gmt_lstm_layer_fwd(const float* x, const float* pregates, const float* w_ih_pk, const float* w_hh_pk,
+                                  const float* bias, const int* lengths, float* gates, float* c_all, float* h_all,
+                                  float* h_final, int L, int B, int I, int H, int ndir, hipStream_t stream)
+{
+    GMT_CHECK_ARG(w_hh_pk && L >= 1 && B >= GMT_TM && (B % GMT_TM) == 0 && (ndir == 1 || ndir == 2));
+    GMT_CHECK_ARG((x != nullptr) != (pregates != nullptr));
+    if (x) GMT_CHECK_ARG(w_ih_pk && bias && (I == H || I == 2 * H));
+    switch (H) {
+#define GMT_CASE(NW) case NW * 32: return launch_fwd<NW>(x, pregates, w_ih_pk, w_hh_pk, bias, lengths, gates, c_all, \
+                                                         h_all, h_final, L, B, I, ndir, stream);
+        GMT_CASE(1) GMT_CASE(2) GMT_CASE(4) GMT_CASE(8)
+#undef GMT_CASE
+        default: return GMT_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int gmt_lstm_layer_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths,
+                                  const float* dh_all, const float* dh_final, const float* dgates_extra,
+                                  const float* dc_extra, int L, int B, int H, int ndir, hipStream_t stream)
+{
+    GMT_CHECK_ARG(gates && c_all && w_hh_pkT && L >= 1 && B >= GMT_TM && (B % GMT_TM) == 0 && (ndir == 1 || ndir == 2));
+    switch (H) {
+#define GMT_CASE(NW) case NW * 32: return launch_bwd<NW>(gates, c_all, w_hh_pkT, lengths, dh_all, dh_final, \
+                                                         dgates_extra, dc_extra, L, B, ndir, stream);
+        GMT_CASE(1) GMT_CASE(2) GMT_CASE(4) GMT_CASE(8)
+#undef GMT_CASE
+        default: return GMT_ERR_UNSUPPORTED;
+    }
+}

@@ -1,0 +1,102 @@
+// Building blocks of the persistent LSTM kernels (gfx950, wave64, fp32-input MFMA).
+//
+// Work decomposition shared by every recurrent kernel in this library:
+//   * a workgroup owns a tile of M = 32 trajectories for ALL timesteps (trajectories are
+//     independent, so there is no inter-workgroup synchronisation at all);
+//   * wave w of the workgroup owns hidden units [32w, 32w+32) and, for those units, all
+//     four gates: its 32x32 accumulator tiles g = 0..3 (i, f, g, o) hold the same
+//     (row, unit) element in the same (lane, register), so the gate non-linearities and
+//     the cell update happen in registers with no data movement;
+//   * the contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32: the result is a
+//     k-ordered fmaf chain, which keeps the 1e-4 parity budget);  operand maps
+//     (cdna_hip_programming.md section 3):
+//        A: lane l holds A[m = l & 31][k = l >> 5]          (one VGPR per 2 k)
+//        B: lane l holds B[k = l >> 5][n = l & 31]
+//        C/D: lane l, reg r holds C[m = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][n = l & 31]
+//   * the A operand (x_t or h_{t-1} of the 32 rows) lives in LDS TRANSPOSED, [k][m] with a
+//     row pitch of 33 floats: the 32 lanes of a half-wave read 32 consecutive floats
+//     (conflict-free ds_read_b32) and the transposing writes hit 32 distinct banks;
+//   * the B operand (weights) is pre-packed once per optimizer step into the exact
+//     per-lane fragment order ("fragment-major"), so a wave's weight load is a run of
+//     contiguous 1 KiB float4 loads.  When 4H x H fp32 fits the CU's register file
+//     (H <= 128: 256 VGPRs per lane over 4 waves) the recurrent weights stay RESIDENT in
+//     registers for the whole sequence; otherwise they stream from L2 every step.
+#pragma once
+#include "gmt_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GMT_TM 32          // trajectories per workgroup tile
+#define GMT_LDA 33         // LDS pitch (floats) of a transposed operand row
+
+// row of accumulator register r for this lane
+__device__ __forceinline__ int gmt_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// Fragment-major packing of a [N][K] row-major weight block for the forward contraction
+// out[m][n] += A[m][k] * W[n][k]:   float index of element e (0..3) of lane `lane`,
+// k-step group s4 (k-steps 4*s4 .. 4*s4+3), gate tile g, wave w:
+//   ((((w * (K/8) + s4) * 4 + g) * 64 + lane) * 4 + e)   holds  W[g*H + 32w + (lane&31)][2*(4*s4+e) + (lane>>5)]
+__device__ __host__ __forceinline__ size_t gmt_pk_index(int w, int s4, int g, int lane, int e, int K) {
+    return ((((size_t)w * (K / 8) + s4) * 4 + g) * 64 + lane) * 4 + e;
+}
+
+// acc[g] += A(lds, [K][GMT_LDA]) * Wpk   for one wave; weights streamed from global/L2.
+// wpk points at this wave's packed block (K/8 groups of 4 gates x 64 lanes x float4).
+template <int NG>
+__device__ __forceinline__ void gmt_mma_stream(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
+                                               const float4* __restrict__ wpk, int K, int lane)
+{
+    const int hi = lane >> 5, lo = lane & 31;
+    const int ns4 = K >> 3;
+    float4 wn[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wn[g] = wpk[g * 64 + lane];
+#pragma unroll 1
+    for (int s4 = 0; s4 < ns4; ++s4) {
+        float4 wc[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) wc[g] = wn[g];
+        if (s4 + 1 < ns4) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) wn[g] = wpk[((s4 + 1) * NG + g) * 64 + lane];
+        }
+        const float* ap = lds_a + (8 * s4 + hi) * GMT_LDA + lo;
+        const float a0 = ap[0], a1 = ap[2 * GMT_LDA], a2 = ap[4 * GMT_LDA], a3 = ap[6 * GMT_LDA];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wc[g].x, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wc[g].y, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, wc[g].z, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, wc[g].w, acc[g], 0, 0, 0);
+        }
+    }
+}
+
+// Same contraction with the weights already in registers: wr[g][s], s = k-step (K/2 of them).
+template <int NG, int KS>
+__device__ __forceinline__ void gmt_mma_resident(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
+                                                 const float (&wr)[NG][KS], int lane)
+{
+    const int hi = lane >> 5, lo = lane & 31;
+    const float* ap = lds_a + hi * GMT_LDA + lo;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const float a = ap[2 * s * GMT_LDA];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[g][s], acc[g], 0, 0, 0);
+    }
+}
+
+// load this wave's packed block into registers (KS = K/2 k-steps)
+template <int NG, int KS>
+__device__ __forceinline__ void gmt_load_resident(float (&wr)[NG][KS], const float4* __restrict__ wpk, int lane)
+{
+#pragma unroll
+    for (int s4 = 0; s4 < KS / 4; ++s4)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float4 v = wpk[(s4 * NG + g) * 64 + lane];
+            wr[g][4 * s4 + 0] = v.x; wr[g][4 * s4 + 1] = v.y; wr[g][4 * s4 + 2] = v.z; wr[g][4 * s4 + 3] = v.w;
+        }
+}

@@ -78,6 +78,42 @@ int gmt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                   hipStream_t stream);
 
+/* ---- persistent LSTM layer (discriminator BiLSTM) ----------------------------------------
+ * gmt_pack_weight: re-orders a weight block into the per-lane MFMA fragment order the
+ * recurrent kernels stream (see csrc/lstm_tile.h).  The logical operand is B[k][n] =
+ * src[k*stride_k + n*stride_n] with n = g*gate_stride + 32*w + j (g < n_gates, w < n_waves,
+ * j < 32); rows k >= k_valid are zero padding up to K (K % 8 == 0).  dst holds
+ * n_waves*n_gates*32*K floats.  Run once per optimizer step per weight. */
+int gmt_pack_weight(const float* src, float* dst, int K, int k_valid, int n_waves, int n_gates,
+                    int gate_stride, long long stride_k, long long stride_n, hipStream_t stream);
+
+/* gmt_lstm_layer_fwd: one layer, ndir directions, all timesteps of a packed (per-row
+ * length-masked) LSTM.  Replaces the torch.nn.LSTM call at RG.py:772 (construction
+ * RG.py:720-727; gate order i,f,g,o).  H in {32, 64, 128, 256}.
+ *   x        [L][B][I]   layer input (fused input contraction), or NULL with
+ *   pregates [ndir][L][B][4H] = x W_ih^T + b_ih + b_hh precomputed by the caller
+ *   w_ih_pk  [ndir] packed (K = I,  n_gates 4, gate_stride H, stride_k 1, stride_n I)
+ *   w_hh_pk  [ndir] packed (K = H,  same form)
+ *   bias     [ndir][4H]  b_ih + b_hh (only read with x)
+ *   lengths  [B] int32 or NULL (= L); clamped to [1, L] as RG.py:766 does
+ * outputs (each may be NULL): gates [ndir][L][B][4H] activated i,f,g,o (may alias
+ * pregates), c_all [ndir][L][B][H], h_all [L][B][ndir*H] (zero at padded steps),
+ * h_final [B][ndir*H] (forward: state at len-1; reverse: state after t = 0, RG.py:776-778). */
+int gmt_lstm_layer_fwd(const float* x, const float* pregates, const float* w_ih_pk, const float* w_hh_pk,
+                       const float* bias, const int* lengths, float* gates, float* c_all, float* h_all,
+                       float* h_final, int L, int B, int I, int H, int ndir, hipStream_t stream);
+
+/* gmt_lstm_layer_bwd: reverse sweep of the same layer (what autograd does for RG.py:1021,
+ * 1109).  In: gates / c_all saved by the forward, dh_all [L][B][ndir*H] and / or dh_final
+ * [B][ndir*H] (either may be NULL), w_hh_pkT [ndir] packed (K = 4H, n_gates 1,
+ * stride_k H, stride_n 1).  Out: `gates` is overwritten with d(pre-activation) (zero at
+ * padded steps); the caller contracts it with x / h_prev / W_ih for dW and dx.
+ * dgates_extra / dc_extra: optional additional adjoints of the saved activations (used by
+ * the gradient-penalty double backward).  H in {32, 64, 128}. */
+int gmt_lstm_layer_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths,
+                       const float* dh_all, const float* dh_final, const float* dgates_extra,
+                       const float* dc_extra, int L, int B, int H, int ndir, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
