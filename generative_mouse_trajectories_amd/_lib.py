@@ -22,6 +22,21 @@ c_ll = ctypes.c_longlong
 c_f = ctypes.c_float
 c_d = ctypes.c_double
 
+
+
+class GenFwdArgs(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in ('g0', 'w_u_pk', 'w_hh0_pk', 'w_ih1_pk', 'w_hh1_pk', 'bias1', 'w1_pk', 'b1', 'w2',
+                                   'b2', 'starts', 'ends', 'init_in', 'target', 'tf_mask', 'out_seq', 'gates0',
+                                   'c0_all', 'h0_all', 'gates1', 'c1_all', 'h1_all', 'u_all', 'y_all', 'oraw_all')] \
+        + [('T', c_i), ('B', c_i), ('H', c_i)]
+
+
+class GenBwdArgs(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in ('gates0', 'c0_all', 'gates1', 'c1_all', 'y_all', 'oraw_all', 'u_all', 'd_out',
+                                   'w1T_pk', 'w_l1T_pk', 'w_hh0T_pk', 'w_uP', 'w2', 'tf_mask', 'd_ypre', 'd_o',
+                                   'd_in0')] + [('T', c_i), ('B', c_i), ('H', c_i)]
+
+
 _SIGS = {
     'gmt_version': [],
     'gmt_kinematics_fwd': [c_p, c_p, c_p, c_i, c_i, c_f, c_p],
@@ -29,9 +44,11 @@ _SIGS = {
     'gmt_telemetry_kinematics_f64': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_d, c_d, c_p],
     'gmt_telemetry_derived_f64': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_p],
     'gmt_adam_step': [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_f, c_p],
-    'gmt_pack_weight': [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_p],
+    'gmt_pack_weight': [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_p],
     'gmt_lstm_layer_fwd': [c_p] * 10 + [c_i] * 5 + [c_p],
     'gmt_lstm_layer_bwd': [c_p] * 8 + [c_i] * 4 + [c_p],
+    'gmt_gen_rollout_fwd': [c_p, c_p],
+    'gmt_gen_rollout_bwd': [c_p, c_p],
 }
 
 

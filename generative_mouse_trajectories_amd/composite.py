@@ -1,0 +1,79 @@
+"""Twice-differentiable discriminator forward out of plain torch ops ON THE GPU, used only by
+the WGAN-GP gradient penalty (RecurrentGAN.py:790-842), which needs the gradient of a
+gradient through the BiLSTM, the spectral-norm linears and the kinematic features.
+
+This is the interim path for the penalty sub-batch (25 % of the batch every 4th step): the
+hand-written kernels of ops.py implement first-order backward only.  It is not a CPU
+fallback - it refuses CPU tensors like the rest of the package - and it shares the
+Discriminator's parameters and spectral-norm buffers (one power iteration per call, like
+any other forward)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L_
+
+
+def kinematics_torch(pos: torch.Tensor, dts: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """Time-major RecurrentGAN.py:315-389: pos [L,B,2], dts [L,B] -> [L,B,9]."""
+    x, y = pos[..., 0], pos[..., 1]
+    z1 = torch.zeros_like(x[:1])
+    dx = torch.cat([z1, x[1:] - x[:-1]], 0)
+    dy = torch.cat([z1, y[1:] - y[:-1]], 0)
+    td = dts + eps
+    vel = torch.sqrt(dx * dx + dy * dy + eps) / td
+    vx, vy = dx / td, dy / td
+    dt_mid = (dts[1:] + dts[:-1]) / 2 + eps
+    acc = torch.cat([z1, (vel[1:] - vel[:-1]) / dt_mid], 0)
+    if pos.shape[0] >= 3:
+        jerk = torch.cat([z1, z1, (acc[2:] - acc[1:-1]) / (dt_mid[1:] + eps)], 0)
+    else:
+        jerk = torch.zeros_like(acc)
+    ax = torch.cat([z1, (vx[1:] - vx[:-1]) / dt_mid], 0)
+    ay = torch.cat([z1, (vy[1:] - vy[:-1]) / dt_mid], 0)
+    curv = (vx * ay - vy * ax).abs() / (vx * vx + vy * vy + eps) ** 1.5
+    return torch.stack([x, y, dx, dy, dts, vel.clamp(0, 100), acc.clamp(-1000, 1000),
+                        jerk.clamp(-10000, 10000), curv.clamp(0, 100)], dim=-1)
+
+
+def _lstm_dir(x, lengths, w_ih, w_hh, b_ih, b_hh, reverse: bool):
+    L, B, _ = x.shape
+    H = w_hh.shape[1]
+    pre = F.linear(x, w_ih, b_ih + b_hh)                       # all timesteps at once
+    h = x.new_zeros(B, H)
+    c = x.new_zeros(B, H)
+    outs = [None] * L
+    w_hh_t = w_hh.t()
+    steps = torch.arange(L, device=x.device)
+    act_all = (steps[:, None] < lengths[None, :]).to(x.dtype).unsqueeze(-1)      # [L,B,1]
+    for t in (range(L - 1, -1, -1) if reverse else range(L)):
+        a = pre[t] + h @ w_hh_t
+        i, f, g, o = a.chunk(4, dim=1)
+        c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h2 = torch.sigmoid(o) * torch.tanh(c2)
+        m = act_all[t]
+        h = m * h2 + (1 - m) * h
+        c = m * c2 + (1 - m) * c
+        outs[t] = m * h2
+    return torch.stack(outs, 0), h
+
+
+def discriminator_forward_torch(D, trajectories: torch.Tensor, dts: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+    """Same mathematics as Discriminator.forward (RecurrentGAN.py:739-783), batch-first in/out."""
+    L_.require_cuda(trajectories, dts)
+    cfg = D.config
+    pos = trajectories.transpose(0, 1)
+    d = dts.transpose(0, 1)
+    lens = lengths.to(trajectories.device).clamp(min=1)
+    x = D.feature_encoder(kinematics_torch(pos, d))
+    hf = hb = None
+    nl = cfg.discriminator_num_layers
+    for l in range(nl):
+        w = D.lstm.layer_weights(l)
+        of, hf = _lstm_dir(x, lens, w[0], w[1], w[2], w[3], False)
+        ob, hb = _lstm_dir(x, lens, w[4], w[5], w[6], w[7], True)
+        x = torch.cat([of, ob], dim=-1)
+        if l + 1 < nl and D.training and cfg.lstm_dropout > 0:
+            x = F.dropout(x, cfg.lstm_dropout, True)
+    return D.output_layers(torch.cat([hf, hb], dim=-1))

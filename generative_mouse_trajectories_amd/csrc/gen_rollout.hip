@@ -1,0 +1,426 @@
+// Persistent autoregressive generator rollout - Generator.forward, RecurrentGAN.py:508-604:
+// the whole T-step loop (dynamic features -> 2-layer LSTM cell -> output head ->
+// softplus -> position update -> teacher-forcing select) is ONE launch, forward, and one
+// launch, backward (BPTT incl. the position / next-input feedback paths).
+//
+// Workgroup = tile of 32 trajectories for all T steps (lstm_tile.h decomposition).
+//   * the time-invariant part of the layer-0 input contraction, condition . W_ih[:, 3:3+H]^T
+//     + b_ih + b_hh, is hoisted out of the loop by the caller (g0, one GEMM per sequence);
+//   * the 7 per-step inputs (current (dx,dy,dt) + 4 dynamic features, RG.py:486-506) are a
+//     K = 8 MFMA contraction;
+//   * layer-0 W_hh stays resident in registers when H <= 128; layer-1 W_ih / W_hh and the
+//     head stream from L2 in fragment-major order;
+//   * per-row scalars (position, current input, teacher-forcing position) live in the
+//     registers of threads 0..31.
+// Teacher forcing is a per-step host decision for the whole batch (RG.py:588): tf_mask[t].
+#include "lstm_tile.h"
+
+namespace {
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // F.softplus
+__device__ __forceinline__ float lrelu_f(float x) { return x > 0.f ? x : 0.2f * x; }
+
+template <int NW, bool RES0>
+__global__ __launch_bounds__(NW * 64, 1)
+void gen_fwd_kernel(gmt_gen_fwd_args a)
+{
+    constexpr int H = NW * 32, KS = H / 2, HH = H / 2, NH = (HH + 31) / 32, NT = NW * 64;
+    extern __shared__ float smem[];
+    float* h0T = smem;                                 // [2][H][LDA]
+    float* h1T = h0T + 2 * H * GMT_LDA;                // [2][H][LDA]
+    float* yT = h1T + 2 * H * GMT_LDA;                 // [NH*32][LDA]
+    float* uT = yT + NH * 32 * GMT_LDA;                // [8][LDA]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * GMT_TM;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int col = wave * 32 + lo;
+    const int T = a.T, B = a.B;
+
+    const float4* wu = reinterpret_cast<const float4*>(a.w_u_pk) + (size_t)wave * 1 * 4 * 64;
+    const float4* whh0 = reinterpret_cast<const float4*>(a.w_hh0_pk) + (size_t)wave * (H / 8) * 4 * 64;
+    const float4* wih1 = reinterpret_cast<const float4*>(a.w_ih1_pk) + (size_t)wave * (H / 8) * 4 * 64;
+    const float4* whh1 = reinterpret_cast<const float4*>(a.w_hh1_pk) + (size_t)wave * (H / 8) * 4 * 64;
+    const float4* w1 = reinterpret_cast<const float4*>(a.w1_pk) + (size_t)wave * (H / 8) * 64;
+
+    float wr0[4][RES0 ? KS : 1];
+    if constexpr (RES0) gmt_load_resident<4, KS>(wr0, whh0, lane);
+
+    for (int i = tid; i < 4 * H * GMT_LDA + NH * 32 * GMT_LDA + 8 * GMT_LDA; i += NT) smem[i] = 0.f;
+
+    float bz1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bz1[g] = a.bias1[g * H + col];
+    const float b1v = (col < HH) ? a.b1[col] : 0.f;
+
+    float c0[16], c1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+
+    // per-row scalar state (threads 0..31 own row tid)
+    float px = 0.f, py = 0.f, ex = 0.f, ey = 0.f, tpx = 0.f, tpy = 0.f, in0 = 0.f, in1 = 0.f, in2 = 0.f;
+    if (tid < GMT_TM) {
+        const size_t row = (size_t)row0 + tid;
+        px = a.starts[row * 2]; py = a.starts[row * 2 + 1];
+        ex = a.ends[row * 2]; ey = a.ends[row * 2 + 1];
+        tpx = px; tpy = py;
+        in0 = a.init_in[0]; in1 = a.init_in[1]; in2 = a.init_in[2];
+    }
+    const size_t lane_row = (size_t)row0 + 4 * hi;
+    int cur = 0;
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        const size_t rs = (size_t)t * B + lane_row;
+        // ---- S1: dynamic features of the current position (RG.py:486-506) + current input
+        if (tid < GMT_TM) {
+            const float rx = ex - px, ry = ey - py;
+            const float dist = sqrtf(rx * rx + ry * ry + 1e-8f);
+            const float ang = atan2f(ry, rx);
+            uT[0 * GMT_LDA + tid] = in0; uT[1 * GMT_LDA + tid] = in1; uT[2 * GMT_LDA + tid] = in2;
+            uT[3 * GMT_LDA + tid] = rx; uT[4 * GMT_LDA + tid] = ry; uT[5 * GMT_LDA + tid] = dist;
+            uT[6 * GMT_LDA + tid] = ang; uT[7 * GMT_LDA + tid] = 0.f;
+            if (a.u_all) {
+                float4* up = reinterpret_cast<float4*>(a.u_all + ((size_t)t * B + row0 + tid) * 8);
+                up[0] = make_float4(in0, in1, in2, rx);
+                up[1] = make_float4(ry, dist, ang, 0.f);
+            }
+        }
+        __syncthreads();
+        // ---- S2: layer 0
+        {
+            f32x16 acc[4];
+            const float* gp = gmt_opaque_v(a.g0 + lane_row * (4 * H) + col);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = gp[(size_t)((r & 3) + 8 * (r >> 2)) * (4 * H) + g * H];
+            gmt_mma_stream<4>(acc, uT, wu, 8, lane);
+            if constexpr (RES0) gmt_mma_resident<4, KS>(acc, h0T + (size_t)cur * H * GMT_LDA, wr0, lane);
+            else gmt_mma_stream<4>(acc, h0T + (size_t)cur * H * GMT_LDA, whh0, H, lane);
+            float* hn = h0T + (size_t)(cur ^ 1) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
+            float* sg = a.gates0 ? a.gates0 + rs * (4 * H) + col : nullptr;
+            float* sc = a.c0_all ? a.c0_all + rs * H + col : nullptr;
+            float* sh = a.h0_all ? a.h0_all + rs * H + col : nullptr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = (r & 3) + 8 * (r >> 2);
+                const float ig = gmt_sigmoid(acc[0][r]), fg = gmt_sigmoid(acc[1][r]);
+                const float gg = gmt_tanh(acc[2][r]), og = gmt_sigmoid(acc[3][r]);
+                const float cn = fg * c0[r] + ig * gg;
+                const float hv = og * gmt_tanh(cn);
+                c0[r] = cn;
+                hn[mr] = hv;
+                if (sg) { float* q = sg + (size_t)mr * (4 * H); q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og; }
+                if (sc) sc[(size_t)mr * H] = cn;
+                if (sh) sh[(size_t)mr * H] = hv;
+            }
+        }
+        __syncthreads();
+        // ---- S3: layer 1
+        {
+            f32x16 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = bz1[g];
+            gmt_mma_stream<4>(acc, h0T + (size_t)(cur ^ 1) * H * GMT_LDA, wih1, H, lane);
+            gmt_mma_stream<4>(acc, h1T + (size_t)cur * H * GMT_LDA, whh1, H, lane);
+            float* hn = h1T + (size_t)(cur ^ 1) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
+            float* sg = a.gates1 ? a.gates1 + rs * (4 * H) + col : nullptr;
+            float* sc = a.c1_all ? a.c1_all + rs * H + col : nullptr;
+            float* sh = a.h1_all ? a.h1_all + rs * H + col : nullptr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = (r & 3) + 8 * (r >> 2);
+                const float ig = gmt_sigmoid(acc[0][r]), fg = gmt_sigmoid(acc[1][r]);
+                const float gg = gmt_tanh(acc[2][r]), og = gmt_sigmoid(acc[3][r]);
+                const float cn = fg * c1[r] + ig * gg;
+                const float hv = og * gmt_tanh(cn);
+                c1[r] = cn;
+                hn[mr] = hv;
+                if (sg) { float* q = sg + (size_t)mr * (4 * H); q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og; }
+                if (sc) sc[(size_t)mr * H] = cn;
+                if (sh) sh[(size_t)mr * H] = hv;
+            }
+        }
+        __syncthreads();
+        // ---- S4: head layer 1, Linear(H -> H/2) + LeakyReLU (RG.py:460-462)
+        if (wave < NH) {
+            f32x16 acc[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = b1v;
+            gmt_mma_stream<1>(acc, h1T + (size_t)(cur ^ 1) * H * GMT_LDA, w1, H, lane);
+            float* yp = yT + col * GMT_LDA + 4 * hi;
+            float* sy = (a.y_all && col < HH) ? a.y_all + rs * HH + col : nullptr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = (r & 3) + 8 * (r >> 2);
+                const float y = lrelu_f(acc[0][r]);
+                yp[mr] = y;
+                if (sy) sy[(size_t)mr * HH] = y;
+            }
+        }
+        __syncthreads();
+        // ---- S5: Linear(H/2 -> 3), softplus on dt, position / next-input update (RG.py:574-595)
+        if (tid < GMT_TM) {
+            const float* w2 = gmt_opaque_s(a.w2);
+            const float* b2 = gmt_opaque_s(a.b2);
+            float o0 = b2[0], o1 = b2[1], o2 = b2[2];
+#pragma unroll 8
+            for (int k = 0; k < HH; ++k) {
+                const float y = yT[k * GMT_LDA + tid];
+                o0 = fmaf(y, w2[k], o0);
+                o1 = fmaf(y, w2[HH + k], o1);
+                o2 = fmaf(y, w2[2 * HH + k], o2);
+            }
+            const float dt = softplus_f(o2) + 0.001f;
+            const size_t ro = ((size_t)t * B + row0 + tid) * 3;
+            a.out_seq[ro] = o0; a.out_seq[ro + 1] = o1; a.out_seq[ro + 2] = dt;
+            if (a.oraw_all) a.oraw_all[(size_t)t * B + row0 + tid] = o2;
+            px += o0; py += o1;                                          // RG.py:585
+            bool tf = false;
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+            if (a.target) {
+                t0 = a.target[ro]; t1 = a.target[ro + 1]; t2 = a.target[ro + 2];
+                tpx += t0; tpy += t1;                                    // running form of RG.py:591-593
+                tf = a.tf_mask && a.tf_mask[t];
+            }
+            if (tf) { in0 = t0; in1 = t1; in2 = t2; px = tpx; py = tpy; }
+            else { in0 = o0; in1 = o1; in2 = dt; }
+        }
+        cur ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------- backward
+__device__ __forceinline__ void cell_bwd(float dht, float& dc, float ig, float fg, float gg, float og,
+                                         float cn, float cp, float& dai, float& daf, float& dag, float& dao)
+{
+    const float tc = gmt_tanh(cn);
+    const float dog = dht * tc;
+    const float dct = dc + dht * og * (1.f - tc * tc);
+    dai = dct * gg * ig * (1.f - ig);
+    daf = dct * cp * fg * (1.f - fg);
+    dag = dct * ig * (1.f - gg * gg);
+    dao = dog * og * (1.f - og);
+    dc = dct * fg;
+}
+
+template <int NW, bool RES0>
+__global__ __launch_bounds__(NW * 64, 1)
+void gen_bwd_kernel(gmt_gen_bwd_args a)
+{
+    constexpr int H = NW * 32, HH = H / 2, NT = NW * 64, NP = NT / 32;
+    constexpr int KS4 = 2 * H;                         // k-steps over K = 4H
+    extern __shared__ float smem[];
+    float* daT = smem;                                 // [4H][LDA]
+    float* dyT = daT + 4 * H * GMT_LDA;                // [HH][LDA]; later aliased by the du partials [NP][8][32]
+    float* doS = dyT + HH * GMT_LDA;                   // [3][32]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * GMT_TM;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int col = wave * 32 + lo;
+    const int T = a.T, B = a.B;
+
+    const float4* w1T = reinterpret_cast<const float4*>(a.w1T_pk) + (size_t)wave * (HH / 8) * 64;
+    const float4* wl1T = reinterpret_cast<const float4*>(a.w_l1T_pk) + (size_t)wave * (4 * H / 8) * 2 * 64;
+    const float4* whh0T = reinterpret_cast<const float4*>(a.w_hh0T_pk) + (size_t)wave * (4 * H / 8) * 64;
+    float wr0[1][RES0 ? KS4 : 1];
+    if constexpr (RES0) gmt_load_resident<1, KS4>(wr0, whh0T, lane);
+
+    float dh0[16], dc0[16], dh1[16], dc1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dh0[r] = 0.f; dc0[r] = 0.f; dh1[r] = 0.f; dc1[r] = 0.f; }
+    float din0 = 0.f, din1 = 0.f, din2 = 0.f, dpx = 0.f, dpy = 0.f;    // carried (threads 0..31)
+    const size_t lane_row = (size_t)row0 + 4 * hi;
+
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t rs = (size_t)t * B + lane_row;
+        const bool tf = a.tf_mask && a.tf_mask[t];     // input of step t+1 came from the target
+        // ---- B1: gradient of out_t = external + feedback through next input / position
+        if (tid < GMT_TM) {
+            const size_t ro = ((size_t)t * B + row0 + tid) * 3;
+            float g0 = a.d_out[ro], g1 = a.d_out[ro + 1], g2 = a.d_out[ro + 2];
+            if (!tf) { g0 += din0 + dpx; g1 += din1 + dpy; g2 += din2; }
+            else { dpx = 0.f; dpy = 0.f; }             // pos_{t+1} was reset from the targets: path cut
+            const float o2 = a.oraw_all[(size_t)t * B + row0 + tid];
+            const float sg = o2 > 20.f ? 1.f : 1.f / (1.f + expf(-o2));     // d softplus
+            g2 *= sg;
+            doS[0 * 32 + tid] = g0; doS[1 * 32 + tid] = g1; doS[2 * 32 + tid] = g2;
+            a.d_o[ro] = g0; a.d_o[ro + 1] = g1; a.d_o[ro + 2] = g2;
+        }
+        __syncthreads();
+        // ---- B2: head backward, d(ypre) = (d_o W2) * lrelu'
+        const float* w2 = gmt_opaque_s(a.w2);
+        for (int idx = tid; idx < GMT_TM * HH; idx += NT) {
+            const int k = idx % HH, row = idx / HH;
+            const size_t go = ((size_t)t * B + row0 + row) * HH + k;
+            const float y = a.y_all[go];
+            float v = doS[row] * w2[k] + doS[32 + row] * w2[HH + k] + doS[64 + row] * w2[2 * HH + k];
+            v *= (y > 0.f) ? 1.f : 0.2f;
+            dyT[k * GMT_LDA + row] = v;
+            a.d_ypre[go] = v;
+        }
+        __syncthreads();
+        // ---- B3: dh1 += d(ypre) W1 ; layer-1 cell backward -> da1
+        {
+            f32x16 acc[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = dh1[r];
+            gmt_mma_stream<1>(acc, dyT, w1T, HH, lane);
+            float* gp = a.gates1 + rs * (4 * H) + col;
+            const float* cn_p = a.c1_all + rs * H + col;
+            const float* cp_p = a.c1_all + ((size_t)(t > 0 ? t - 1 : 0) * B + lane_row) * H + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = (r & 3) + 8 * (r >> 2), m = mr + 4 * hi;
+                float* q = gp + (size_t)mr * (4 * H);
+                const float cp = t > 0 ? cp_p[(size_t)mr * H] : 0.f;
+                float dai, daf, dag, dao;
+                cell_bwd(acc[0][r], dc1[r], q[0], q[H], q[2 * H], q[3 * H], cn_p[(size_t)mr * H], cp, dai, daf, dag, dao);
+                q[0] = dai; q[H] = daf; q[2 * H] = dag; q[3 * H] = dao;
+                daT[(0 * H + col) * GMT_LDA + m] = dai; daT[(1 * H + col) * GMT_LDA + m] = daf;
+                daT[(2 * H + col) * GMT_LDA + m] = dag; daT[(3 * H + col) * GMT_LDA + m] = dao;
+            }
+        }
+        __syncthreads();
+        // ---- B4: dh1_prev = da1 W_hh1 ; dh0_total = dh0 + da1 W_ih1
+        f32x16 acc2[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc2[0][r] = 0.f; acc2[1][r] = dh0[r]; }
+        gmt_mma_stream<2>(acc2, daT, wl1T, 4 * H, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh1[r] = acc2[0][r];
+        __syncthreads();
+        // ---- B5: layer-0 cell backward -> da0
+        {
+            float* gp = a.gates0 + rs * (4 * H) + col;
+            const float* cn_p = a.c0_all + rs * H + col;
+            const float* cp_p = a.c0_all + ((size_t)(t > 0 ? t - 1 : 0) * B + lane_row) * H + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = (r & 3) + 8 * (r >> 2), m = mr + 4 * hi;
+                float* q = gp + (size_t)mr * (4 * H);
+                const float cp = t > 0 ? cp_p[(size_t)mr * H] : 0.f;
+                float dai, daf, dag, dao;
+                cell_bwd(acc2[1][r], dc0[r], q[0], q[H], q[2 * H], q[3 * H], cn_p[(size_t)mr * H], cp, dai, daf, dag, dao);
+                q[0] = dai; q[H] = daf; q[2 * H] = dag; q[3 * H] = dao;
+                daT[(0 * H + col) * GMT_LDA + m] = dai; daT[(1 * H + col) * GMT_LDA + m] = daf;
+                daT[(2 * H + col) * GMT_LDA + m] = dag; daT[(3 * H + col) * GMT_LDA + m] = dao;
+            }
+        }
+        __syncthreads();
+        // ---- B6: dh0_prev = da0 W_hh0 ; partial d(u) = da0 W_u over this thread's 64-wide k slice
+        {
+            f32x16 acc[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+            if constexpr (RES0) gmt_mma_resident<1, KS4>(acc, daT, wr0, lane);
+            else gmt_mma_stream<1>(acc, daT, whh0T, 4 * H, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh0[r] = acc[0][r];
+            const int part = tid >> 5, row = tid & 31;
+            float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const int k0 = part * 64;
+            const float* wup = gmt_opaque_s(a.w_uP);
+#pragma unroll 4
+            for (int k = k0; k < k0 + 64; ++k) {
+                const float d = daT[k * GMT_LDA + row];
+                const float4 wa = reinterpret_cast<const float4*>(wup + (size_t)k * 8)[0];
+                const float4 wb = reinterpret_cast<const float4*>(wup + (size_t)k * 8)[1];
+                s[0] = fmaf(d, wa.x, s[0]); s[1] = fmaf(d, wa.y, s[1]); s[2] = fmaf(d, wa.z, s[2]);
+                s[3] = fmaf(d, wa.w, s[3]); s[4] = fmaf(d, wb.x, s[4]); s[5] = fmaf(d, wb.y, s[5]);
+                s[6] = fmaf(d, wb.z, s[6]);
+            }
+            float* pp = dyT + (size_t)part * 8 * 32 + row;   // aliases dyT (dead since B3)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) pp[j * 32] = s[j];
+        }
+        __syncthreads();
+        // ---- B7: reduce d(u); dynamic-feature backward (RG.py:502-506) -> d(pos_t); carry
+        if (tid < GMT_TM) {
+            float du[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) du[j] += dyT[(size_t)p * 8 * 32 + j * 32 + tid];
+            const float* up = a.u_all + ((size_t)t * B + row0 + tid) * 8;
+            const float rx = up[3], ry = up[4], dist = up[5];
+            const float r2 = rx * rx + ry * ry;
+            const float inv = r2 > 0.f ? 1.f / r2 : 0.f;
+            const float drx = du[3] + du[5] * rx / dist - du[6] * ry * inv;
+            const float dry = du[4] + du[5] * ry / dist + du[6] * rx * inv;
+            // rem = end - pos  ->  d(pos_t) = -d(rem) + what flows on to pos_{t+1}
+            dpx = dpx - drx; dpy = dpy - dry;
+            din0 = du[0]; din1 = du[1]; din2 = du[2];
+            if (t == 0) {
+                float* o = a.d_in0 + ((size_t)row0 + tid) * 3;
+                o[0] = din0; o[1] = din1; o[2] = din2;
+            }
+        }
+    }
+}
+
+template <int NW>
+int launch_gen_fwd(const gmt_gen_fwd_args& a, hipStream_t stream)
+{
+    constexpr int H = NW * 32, HH = H / 2, NH = (HH + 31) / 32;
+    constexpr bool RES0 = (NW <= 4);
+    const size_t lds = (size_t)(4 * H + NH * 32 + 8) * GMT_LDA * sizeof(float);
+    if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;
+    auto k = gen_fwd_kernel<NW, RES0>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return GMT_ERR_HIP;
+    hipLaunchKernelGGL(k, dim3(a.B / GMT_TM), dim3(NW * 64), lds, stream, a);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+template <int NW>
+int launch_gen_bwd(const gmt_gen_bwd_args& a, hipStream_t stream)
+{
+    constexpr int H = NW * 32, HH = H / 2;
+    constexpr bool RES0 = (NW <= 4);
+    const size_t lds = ((size_t)(4 * H + HH) * GMT_LDA + 96) * sizeof(float);
+    if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;
+    auto k = gen_bwd_kernel<NW, RES0>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return GMT_ERR_HIP;
+    hipLaunchKernelGGL(k, dim3(a.B / GMT_TM), dim3(NW * 64), lds, stream, a);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+}  // namespace
+
+extern "C" int gmt_gen_rollout_fwd(const gmt_gen_fwd_args* a, hipStream_t stream)
+{
+    GMT_CHECK_ARG(a && a->g0 && a->w_u_pk && a->w_hh0_pk && a->w_ih1_pk && a->w_hh1_pk && a->bias1 && a->w1_pk &&
+                  a->b1 && a->w2 && a->b2 && a->starts && a->ends && a->init_in && a->out_seq);
+    GMT_CHECK_ARG(a->T >= 1 && a->B >= GMT_TM && (a->B % GMT_TM) == 0);
+    switch (a->H) {
+        case 32: return launch_gen_fwd<1>(*a, stream);
+        case 64: return launch_gen_fwd<2>(*a, stream);
+        case 128: return launch_gen_fwd<4>(*a, stream);
+        case 256: return launch_gen_fwd<8>(*a, stream);
+        default: return GMT_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int gmt_gen_rollout_bwd(const gmt_gen_bwd_args* a, hipStream_t stream)
+{
+    GMT_CHECK_ARG(a && a->gates0 && a->c0_all && a->gates1 && a->c1_all && a->y_all && a->oraw_all && a->u_all &&
+                  a->d_out && a->w1T_pk && a->w_l1T_pk && a->w_hh0T_pk && a->w_uP && a->w2 && a->d_ypre && a->d_o &&
+                  a->d_in0);
+    GMT_CHECK_ARG(a->T >= 1 && a->B >= GMT_TM && (a->B % GMT_TM) == 0);
+    switch (a->H) {
+        case 32: return launch_gen_bwd<1>(*a, stream);
+        case 64: return launch_gen_bwd<2>(*a, stream);
+        case 128: return launch_gen_bwd<4>(*a, stream);
+        case 256: return launch_gen_bwd<8>(*a, stream);
+        default: return GMT_ERR_UNSUPPORTED;
+    }
+}

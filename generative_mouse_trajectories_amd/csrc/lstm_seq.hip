@@ -16,7 +16,7 @@
 namespace {
 
 // ------------------------------------------------------------------ weight packing
-__global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int k_valid,
+__global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int k_valid, int n_valid,
                             int n_waves, int n_gates, int gate_stride, long long sk, long long sn)
 {
     const long long total = (long long)n_waves * (K / 8) * n_gates * 64 * 4;
@@ -30,7 +30,7 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
         const int w = (int)(q / (K / 8));
         const int k = 2 * (4 * s4 + e) + (lane >> 5);
         const int n = g * gate_stride + 32 * w + (lane & 31);
-        dst[i] = (k < k_valid) ? src[(long long)k * sk + (long long)n * sn] : 0.0f;
+        dst[i] = (k < k_valid && n < n_valid) ? src[(long long)k * sk + (long long)n * sn] : 0.0f;
     }
 }
 
@@ -365,13 +365,14 @@ int launch_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const in
 
 }  // namespace
 
-extern "C" int gmt_pack_weight(const float* src, float* dst, int K, int k_valid, int n_waves, int n_gates,
+extern "C" int gmt_pack_weight(const float* src, float* dst, int K, int k_valid, int n_valid, int n_waves, int n_gates,
                                int gate_stride, long long stride_k, long long stride_n, hipStream_t stream)
 {
-    GMT_CHECK_ARG(src && dst && K >= 8 && (K % 8) == 0 && k_valid >= 1 && k_valid <= K && n_waves >= 1 && n_gates >= 1);
+    GMT_CHECK_ARG(src && dst && K >= 8 && (K % 8) == 0 && k_valid >= 1 && k_valid <= K && n_valid >= 1 &&
+                  n_waves >= 1 && n_gates >= 1);
     const long long total = (long long)n_waves * (K / 8) * n_gates * 256;
     hipLaunchKernelGGL(pack_kernel, dim3(gmt_grid_1d(total, 256)), dim3(256), 0, stream, src, dst, K, k_valid,
-                       n_waves, n_gates, gate_stride, stride_k, stride_n);
+                       n_valid, n_waves, n_gates, gate_stride, stride_k, stride_n);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }

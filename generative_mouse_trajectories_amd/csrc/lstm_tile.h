@@ -29,6 +29,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GMT_TM 32          // trajectories per workgroup tile
 #define GMT_LDA 33         // LDS pitch (floats) of a transposed operand row
 
+// Launders a pointer through an empty asm so that loads through it cannot be hoisted out of
+// the time loop (LICM would otherwise pin dozens of loop-invariant values in VGPRs that the
+// resident weights need).
+template <class T> __device__ __forceinline__ T* gmt_opaque_v(T* p) { asm volatile("" : "+v"(p)); return p; }
+template <class T> __device__ __forceinline__ T* gmt_opaque_s(T* p) { asm volatile("" : "+s"(p)); return p; }
+
 // row of accumulator register r for this lane
 __device__ __forceinline__ int gmt_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

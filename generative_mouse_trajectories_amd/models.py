@@ -1,0 +1,237 @@
+"""Generator / Discriminator with the class surface and state-dict keys of the reference
+(python/learning/RecurrentGAN.py:424-783), computed by the HIP kernels of libgmt_hip.so.
+
+Both modules run on the GPU only.  Internally everything is time-major ([L, B, ...]) and
+the batch is padded to a multiple of 32 rows (one workgroup tile); the public methods
+take and return the reference's batch-first tensors.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L_
+from . import ops
+from .config import Config
+
+
+# ------------------------------------------------------------------------------------------
+# functional API of the reference
+# ------------------------------------------------------------------------------------------
+def compute_kinematics(positions: torch.Tensor, dts: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """RecurrentGAN.py:315-389.  positions (B,L,2), dts (B,L) -> (B,L,9)."""
+    L_.require_cuda(positions, dts)
+    feat = ops.kinematics_tm(positions.transpose(0, 1), dts.transpose(0, 1), eps)
+    return feat.transpose(0, 1)
+
+
+def trajectory_to_absolute(start: torch.Tensor, deltas: torch.Tensor) -> torch.Tensor:
+    """RecurrentGAN.py:392-417.  start (B,2), deltas (B,L,2) -> (B,L+1,2)."""
+    run = torch.cumsum(deltas, dim=1) + start.unsqueeze(1)
+    return torch.cat([start.unsqueeze(1), run], dim=1)
+
+
+def _pad_batch(t: torch.Tensor, Bp: int, dim: int, value: float = 0.0) -> torch.Tensor:
+    B = t.shape[dim]
+    if B == Bp:
+        return t
+    pad = [0, 0] * (t.dim() - dim - 1) + [0, Bp - B]
+    return F.pad(t, pad, value=value)
+
+
+# ------------------------------------------------------------------------------------------
+# spectral-norm linear: parameters / buffers named as torch.nn.utils.spectral_norm names them
+# ------------------------------------------------------------------------------------------
+class SNLinear(nn.Module):
+    """nn.Linear wrapped by the legacy torch.nn.utils.spectral_norm (RG.py:713-736): state
+    `bias`, `weight_orig`, buffers `weight_u`, `weight_v`; one power iteration per
+    training-mode forward, W = W_orig / (u^T W_orig v)."""
+
+    def __init__(self, in_features: int, out_features: int, eps: float = 1e-12):
+        super().__init__()
+        lin = nn.Linear(in_features, out_features)               # same init draws as the reference
+        self.in_features, self.out_features, self.eps = in_features, out_features, eps
+        self.bias = nn.Parameter(lin.bias.detach().clone())
+        self.weight_orig = nn.Parameter(lin.weight.detach().clone())
+        u = F.normalize(torch.empty(out_features).normal_(0, 1), dim=0, eps=eps)
+        v = F.normalize(torch.empty(in_features).normal_(0, 1), dim=0, eps=eps)
+        self.register_buffer('weight_u', u)
+        self.register_buffer('weight_v', v)
+
+    def compute_weight(self) -> torch.Tensor:
+        w = self.weight_orig
+        u, v = self.weight_u, self.weight_v
+        if self.training:
+            with torch.no_grad():
+                v = F.normalize(torch.mv(w.t(), u), dim=0, eps=self.eps, out=v)
+                u = F.normalize(torch.mv(w, v), dim=0, eps=self.eps, out=u)
+                u = u.clone(memory_format=torch.contiguous_format)
+                v = v.clone(memory_format=torch.contiguous_format)
+        sigma = torch.dot(u, torch.mv(w, v))
+        return w / sigma
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return F.linear(x, self.compute_weight(), self.bias)
+
+
+class _LSTMParams(nn.Module):
+    """Holds LSTM parameters under torch.nn.LSTM's names (weight_ih_l0, ..., _reverse) and
+    with its default initialisation; the math runs in the HIP kernels."""
+
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int, bidirectional: bool):
+        super().__init__()
+        ref = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                      batch_first=True, bidirectional=bidirectional)
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.num_layers, self.bidirectional = num_layers, bidirectional
+        for name, p in ref.named_parameters():
+            self.register_parameter(name, nn.Parameter(p.detach().clone()))
+
+    def layer_weights(self, layer: int) -> List[torch.Tensor]:
+        out = []
+        for sfx in (('', '_reverse') if self.bidirectional else ('',)):
+            out += [getattr(self, f'weight_ih_l{layer}{sfx}'), getattr(self, f'weight_hh_l{layer}{sfx}'),
+                    getattr(self, f'bias_ih_l{layer}{sfx}'), getattr(self, f'bias_hh_l{layer}{sfx}')]
+        return out
+
+
+# ------------------------------------------------------------------------------------------
+# Generator (RecurrentGAN.py:424-690)
+# ------------------------------------------------------------------------------------------
+class Generator(nn.Module):
+    def __init__(self, config: Config):
+        super().__init__()
+        self.config = config
+        H = config.generator_hidden_dim
+        if config.generator_num_layers != 2:
+            raise NotImplementedError('the fused rollout kernel implements the reference default of 2 LSTM layers')
+        if H % 32 != 0 or H > 256:
+            raise NotImplementedError('generator_hidden_dim must be a multiple of 32, at most 256')
+        self.condition_encoder = nn.Sequential(
+            nn.Linear(6 + config.latent_dim, H), nn.LayerNorm(H), nn.LeakyReLU(0.2),
+            nn.Linear(H, H), nn.LayerNorm(H), nn.LeakyReLU(0.2))
+        self.lstm = _LSTMParams(3 + H + 4, H, config.generator_num_layers, False)
+        self.output_layer = nn.Sequential(nn.Linear(H, H // 2), nn.LeakyReLU(0.2), nn.Linear(H // 2, 3))
+        self.initial_input = nn.Parameter(torch.zeros(1, 1, 3))
+
+    def _compute_condition(self, start, end, z):
+        diff = end - start
+        distance = torch.sqrt((diff ** 2).sum(dim=-1, keepdim=True) + 1e-8)
+        angle = torch.atan2(diff[:, 1:2], diff[:, 0:1])
+        return self.condition_encoder(torch.cat([start, end, distance, angle, z], dim=-1))
+
+    def _rollout(self, start, end, z, target_tm: Optional[torch.Tensor], tf_mask: Optional[torch.Tensor], T: int):
+        """start/end (B,2), z (B,latent), target_tm (T,B,3) -> out (T,B,3); pads B to 32."""
+        L_.require_cuda(start, end, z)
+        H = self.config.generator_hidden_dim
+        B = start.shape[0]
+        Bp = ops.pad_rows(B)
+        cond = self._compute_condition(start, end, z)
+        lp = self.lstm
+        w_ih0 = lp.weight_ih_l0
+        g0 = F.linear(cond, w_ih0[:, 3:3 + H], lp.bias_ih_l0 + lp.bias_hh_l0)
+        w_u = torch.cat([w_ih0[:, :3], w_ih0[:, 3 + H:]], dim=1)
+        bias1 = lp.bias_ih_l1 + lp.bias_hh_l1
+        g0 = _pad_batch(g0, Bp, 0)
+        s_p, e_p = _pad_batch(start, Bp, 0), _pad_batch(end, Bp, 0)
+        if target_tm is not None:
+            target_tm = _pad_batch(target_tm, Bp, 1).contiguous()
+        out = ops.GenRolloutFn.apply(g0, w_u, lp.weight_hh_l0, lp.weight_ih_l1, lp.weight_hh_l1, bias1,
+                                     self.output_layer[0].weight, self.output_layer[0].bias,
+                                     self.output_layer[2].weight, self.output_layer[2].bias,
+                                     self.initial_input, s_p, e_p, target_tm, tf_mask, T)
+        return out[:, :B]
+
+    def forward(self, start, end, z, target_sequences: Optional[torch.Tensor] = None,
+                target_lengths: Optional[torch.Tensor] = None, teacher_forcing_ratio: float = 0.0,
+                tf_mask: Optional[Sequence[bool]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """RecurrentGAN.py:508-604.  `tf_mask` (optional, length T) replaces the per-step coin
+        `torch.rand(1) < teacher_forcing_ratio` (RG.py:588) with explicit outcomes."""
+        B = start.shape[0]
+        if self.training and self.config.lstm_dropout > 0:
+            raise NotImplementedError('inter-layer LSTM dropout is not fused into the rollout kernel yet; '
+                                      'set config.lstm_dropout = 0')
+        if target_sequences is not None:
+            T = target_sequences.shape[1]
+            if tf_mask is None:
+                # one host coin per step for the whole batch, drawn every step like the reference
+                tf_mask = [torch.rand(1).item() < teacher_forcing_ratio for _ in range(T)]
+            tm = None
+            if any(tf_mask):
+                tm = torch.tensor([1 if b else 0 for b in tf_mask], dtype=torch.uint8).to(start.device)
+            out = self._rollout(start, end, z, target_sequences.transpose(0, 1), tm, T)
+        else:
+            T = self.config.max_generation_steps
+            out = self._rollout(start, end, z, None, None, T)
+        outputs = out.transpose(0, 1)
+        if target_lengths is not None:
+            lengths = target_lengths
+        else:
+            lengths = torch.full((B,), T, device=start.device)
+        return outputs, lengths
+
+    @torch.no_grad()
+    def generate(self, start, end, z: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """RecurrentGAN.py:606-690: sampling with per-sample early stop at distance < threshold.
+        The rollout runs all max_generation_steps in one launch (rows are independent); the stop
+        step of every row and the common truncation point are then read off the positions."""
+        B = start.shape[0]
+        if z is None:
+            z = torch.randn(B, self.config.latent_dim, device=start.device)
+        was_training = self.training
+        self.eval()
+        T = self.config.max_generation_steps
+        out = self._rollout(start, end, z, None, None, T).transpose(0, 1)          # (B,T,3)
+        if was_training:
+            self.train()
+        pos = start.unsqueeze(1) + torch.cumsum(out[:, :, :2], dim=1)
+        dist = torch.sqrt(((pos - end.unsqueeze(1)) ** 2).sum(-1))
+        hit = dist < self.config.distance_threshold                                   # (B,T)
+        steps = torch.arange(1, T + 1, device=start.device).unsqueeze(0).expand(B, T)
+        first = torch.where(hit, steps, torch.full_like(steps, T + 1)).min(dim=1).values
+        t_end = int(min(T, int(first.max().item())))       # the reference breaks once every row is done
+        lengths = torch.where(first <= t_end, first, torch.full_like(first, t_end))
+        return out[:, :t_end].contiguous(), lengths
+
+
+# ------------------------------------------------------------------------------------------
+# Discriminator (RecurrentGAN.py:697-783)
+# ------------------------------------------------------------------------------------------
+class Discriminator(nn.Module):
+    def __init__(self, config: Config):
+        super().__init__()
+        self.config = config
+        H = config.discriminator_hidden_dim
+        if H % 32 != 0 or H > 256:
+            raise NotImplementedError('discriminator_hidden_dim must be a multiple of 32, at most 256')
+        self.feature_encoder = nn.Sequential(SNLinear(9, H), nn.LeakyReLU(0.2), SNLinear(H, H), nn.LeakyReLU(0.2))
+        self.lstm = _LSTMParams(H, H, config.discriminator_num_layers, True)
+        self.output_layers = nn.Sequential(SNLinear(2 * H, H), nn.LeakyReLU(0.2), nn.Dropout(config.head_dropout),
+                                           SNLinear(H, H // 2), nn.LeakyReLU(0.2), SNLinear(H // 2, 1))
+        self.fuse_input_gemm = True
+
+    def forward_tm(self, pos_tm: torch.Tensor, dts_tm: torch.Tensor, lengths_i32: torch.Tensor) -> torch.Tensor:
+        """Time-major core: pos [L,Bp,2], dts [L,Bp], lengths int32 [Bp] (Bp % 32 == 0) -> [Bp,1]."""
+        feat = ops.kinematics_tm(pos_tm, dts_tm)
+        x = self.feature_encoder(feat)
+        nl = self.config.discriminator_num_layers
+        h_final = None
+        for l in range(nl):
+            h_all, h_final = ops.lstm_layer(x, lengths_i32, self.lstm.layer_weights(l), fuse_x=self.fuse_input_gemm)
+            x = h_all
+            if l + 1 < nl and self.training and self.config.lstm_dropout > 0:
+                x = F.dropout(x, self.config.lstm_dropout, True)
+        return self.output_layers(h_final)
+
+    def forward(self, trajectories: torch.Tensor, dts: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+        """trajectories (B,L,2), dts (B,L), lengths (B,) -> critic scores (B,1)."""
+        L_.require_cuda(trajectories, dts)
+        B = trajectories.shape[0]
+        Bp = ops.pad_rows(B)
+        pos_tm = _pad_batch(trajectories.transpose(0, 1), Bp, 1).contiguous()
+        dts_tm = _pad_batch(dts.transpose(0, 1), Bp, 1).contiguous()
+        lens = _pad_batch(lengths.to(device=trajectories.device, dtype=torch.int32).clamp(min=1), Bp, 0, 1)
+        return self.forward_tm(pos_tm, dts_tm, lens.contiguous())[:B]

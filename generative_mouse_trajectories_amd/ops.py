@@ -68,7 +68,7 @@ def pack_forward(ws: List[torch.Tensor], H: int, K: int, col0: int = 0, k_valid:
         w = w.detach()
         assert w.is_contiguous() and w.shape[0] == 4 * H
         src = w.data_ptr() + 4 * col0
-        L_.call('gmt_pack_weight', src, out[d].data_ptr(), K, kv, H // 32, 4, H, 1, w.shape[1], L_.stream())
+        L_.call('gmt_pack_weight', src, out[d].data_ptr(), K, kv, 1 << 30, H // 32, 4, H, 1, w.shape[1], L_.stream())
     return out
 
 
@@ -81,7 +81,7 @@ def pack_transposed(ws: List[torch.Tensor], n_out: int, K: int, col0: int = 0, n
         w = w.detach()
         assert w.is_contiguous() and w.shape[0] == K
         src = w.data_ptr() + 4 * col0
-        L_.call('gmt_pack_weight', src, out[d].data_ptr(), K, K, n_out // 32, 1, 0, w.shape[1], 1, L_.stream())
+        L_.call('gmt_pack_weight', src, out[d].data_ptr(), K, K, 1 << 30, n_out // 32, 1, 0, w.shape[1], 1, L_.stream())
     return out
 
 
@@ -183,3 +183,122 @@ def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
     assert grad.numel() == n and exp_avg.numel() == n and exp_avg_sq.numel() == n
     L_.call('gmt_adam_step', L_.ptr(param), L_.ptr(grad), L_.ptr(exp_avg), L_.ptr(exp_avg_sq), n,
             lr, betas[0], betas[1], eps, step, grad_scale, L_.stream())
+
+
+# ----------------------------------------------------------------------------------------
+# generator rollout (RecurrentGAN.py:508-604)
+# ----------------------------------------------------------------------------------------
+def _pack1(w: torch.Tensor, K: int, k_valid: int, n_valid: int, n_waves: int, n_gates: int, gate_stride: int,
+           stride_k: int, stride_n: int) -> torch.Tensor:
+    w = w.detach().contiguous()
+    out = torch.empty(n_waves * n_gates * 32 * K, device=w.device, dtype=torch.float32)
+    L_.call('gmt_pack_weight', w.data_ptr(), out.data_ptr(), K, k_valid, n_valid, n_waves, n_gates, gate_stride,
+            stride_k, stride_n, L_.stream())
+    return out
+
+
+class GenRolloutFn(torch.autograd.Function):
+    """Inputs (all fp32, cuda):
+      g0 [B,4H], w_u [4H,7], w_hh0 [4H,H], w_ih1 [4H,H], w_hh1 [4H,H], bias1 [4H],
+      w1 [H/2,H], b1 [H/2], w2 [3,H/2], b2 [3], init_in [3], starts [B,2], ends [B,2],
+      target [T,B,3] or None, tf_mask uint8 [T] (device) or None, T.
+    Output: out_seq [T,B,3].  B % 32 == 0."""
+
+    @staticmethod
+    def forward(ctx, g0, w_u, w_hh0, w_ih1, w_hh1, bias1, w1, b1, w2, b2, init_in, starts, ends, target, tf_mask, T):
+        L_.require_cuda(g0)
+        B, H4 = g0.shape
+        H = H4 // 4
+        HH = H // 2
+        NW = H // 32
+        dev = g0.device
+        assert B % TM == 0
+        need_grad = any(ctx.needs_input_grad)
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        a = L_.GenFwdArgs()
+        keep = []
+
+        def P(t):
+            if t is None:
+                return None
+            t = t.detach().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        a.g0 = P(g0)
+        a.w_u_pk = P(_pack1(w_u, 8, 7, 1 << 30, NW, 4, H, 1, 7))
+        a.w_hh0_pk = P(_pack1(w_hh0, H, H, 1 << 30, NW, 4, H, 1, H))
+        a.w_ih1_pk = P(_pack1(w_ih1, H, H, 1 << 30, NW, 4, H, 1, H))
+        a.w_hh1_pk = P(_pack1(w_hh1, H, H, 1 << 30, NW, 4, H, 1, H))
+        a.bias1 = P(bias1)
+        a.w1_pk = P(_pack1(w1, H, H, HH, max(1, H // 64), 1, 0, 1, H))
+        a.b1 = P(b1); a.w2 = P(w2); a.b2 = P(b2)
+        a.starts = P(starts); a.ends = P(ends); a.init_in = P(init_in.reshape(3))
+        a.target = P(target); a.tf_mask = P(tf_mask)
+        out_seq = f(T, B, 3)
+        a.out_seq = out_seq.data_ptr()
+        saved = None
+        if need_grad:
+            saved = dict(gates0=f(T, B, 4 * H), c0=f(T, B, H), h0=f(T, B, H), gates1=f(T, B, 4 * H), c1=f(T, B, H),
+                         h1=f(T, B, H), u=f(T, B, 8), y=f(T, B, HH), oraw=f(T, B))
+            a.gates0 = saved['gates0'].data_ptr(); a.c0_all = saved['c0'].data_ptr(); a.h0_all = saved['h0'].data_ptr()
+            a.gates1 = saved['gates1'].data_ptr(); a.c1_all = saved['c1'].data_ptr(); a.h1_all = saved['h1'].data_ptr()
+            a.u_all = saved['u'].data_ptr(); a.y_all = saved['y'].data_ptr(); a.oraw_all = saved['oraw'].data_ptr()
+        a.T, a.B, a.H = T, B, H
+        L_.call('gmt_gen_rollout_fwd', ctypes_byref(a), L_.stream())
+        if need_grad:
+            ctx.save_for_backward(w_u, w_hh0, w_ih1, w_hh1, w1, w2, tf_mask if tf_mask is not None else torch.empty(0),
+                                  *saved.values())
+            ctx.dims = (T, B, H)
+            ctx.has_tf = tf_mask is not None
+            ctx.init_shape = tuple(init_in.shape)
+        return out_seq
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (w_u, w_hh0, w_ih1, w_hh1, w1, w2, tf_mask, gates0, c0, h0, gates1, c1, h1, u, y, oraw) = ctx.saved_tensors
+        T, B, H = ctx.dims
+        HH, NW = H // 2, H // 32
+        dev = d_out.device
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        d_out = d_out.contiguous()
+        a = L_.GenBwdArgs()
+        w1T = _pack1(w1, HH, HH, 1 << 30, NW, 1, 0, H, 1)
+        wl1 = torch.cat([w_hh1.detach(), w_ih1.detach()], dim=1).contiguous()        # [4H, 2H]
+        wl1T = _pack1(wl1, 4 * H, 4 * H, 1 << 30, NW, 2, H, 2 * H, 1)
+        whh0T = _pack1(w_hh0, 4 * H, 4 * H, 1 << 30, NW, 1, 0, H, 1)
+        w_uP = torch.zeros(4 * H, 8, device=dev, dtype=torch.float32)
+        w_uP[:, :7] = w_u.detach()
+        w2c = w2.detach().contiguous()
+        d_ypre = f(T, B, HH); d_o = f(T, B, 3); d_in0 = f(B, 3)
+        a.gates0 = gates0.data_ptr(); a.c0_all = c0.data_ptr(); a.gates1 = gates1.data_ptr(); a.c1_all = c1.data_ptr()
+        a.y_all = y.data_ptr(); a.oraw_all = oraw.data_ptr(); a.u_all = u.data_ptr(); a.d_out = d_out.data_ptr()
+        a.w1T_pk = w1T.data_ptr(); a.w_l1T_pk = wl1T.data_ptr(); a.w_hh0T_pk = whh0T.data_ptr()
+        a.w_uP = w_uP.data_ptr(); a.w2 = w2c.data_ptr()
+        a.tf_mask = tf_mask.data_ptr() if ctx.has_tf else None
+        a.d_ypre = d_ypre.data_ptr(); a.d_o = d_o.data_ptr(); a.d_in0 = d_in0.data_ptr()
+        a.T, a.B, a.H = T, B, H
+        L_.call('gmt_gen_rollout_bwd', ctypes_byref(a), L_.stream())
+        da0 = gates0.view(T * B, 4 * H)
+        da1 = gates1.view(T * B, 4 * H)
+        h0v, h1v = h0.view(T * B, H), h1.view(T * B, H)
+        d_g0 = gates0.sum(0)                                            # time-invariant input: sum over t
+        d_w_u = torch.mm(da0.t(), u.view(T * B, 8))[:, :7]
+        d_w_hh0 = torch.mm(da0[B:].t(), h0v[:-B]) if T > 1 else torch.zeros_like(w_hh0)
+        d_w_ih1 = torch.mm(da1.t(), h0v)
+        d_w_hh1 = torch.mm(da1[B:].t(), h1v[:-B]) if T > 1 else torch.zeros_like(w_hh1)
+        d_bias1 = da1.sum(0)
+        dyp = d_ypre.view(T * B, HH)
+        d_w1 = torch.mm(dyp.t(), h1v)
+        d_b1 = dyp.sum(0)
+        dov = d_o.view(T * B, 3)
+        d_w2 = torch.mm(dov.t(), y.view(T * B, HH))
+        d_b2 = dov.sum(0)
+        d_init = d_in0.sum(0).reshape(ctx.init_shape)
+        return (d_g0, d_w_u, d_w_hh0, d_w_ih1, d_w_hh1, d_bias1, d_w1, d_b1, d_w2, d_b2, d_init,
+                None, None, None, None, None)
+
+
+def ctypes_byref(a):
+    import ctypes
+    return ctypes.cast(ctypes.pointer(a), ctypes.c_void_p)

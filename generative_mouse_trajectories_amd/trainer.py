@@ -1,0 +1,368 @@
+"""Trainer with the surface of the reference's Trainer (RecurrentGAN.py:845-1303) on top of
+the HIP kernels: same step functions, same returned metric keys, same checkpoint keys.
+
+Differences that are deliberate (documented in DESIGN.md):
+  * parameters, gradients and Adam moments of each model live in ONE flat buffer each, so
+    the optimizer step is a single fused launch (and the data-parallel all-reduce one call);
+  * the step scalars come back in one device-to-host copy instead of 4-5 `.item()` syncs;
+  * the discriminator weight gradients that the reference computes (and throws away) inside
+    the generator step are not computed;
+  * noise (z, teacher-forcing coins, GP indices, alpha) is drawn on the GPU generator unless
+    passed explicitly (`noise=`), which is how the parity tests replay the reference.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.optim.lr_scheduler import ReduceLROnPlateau
+
+from . import _lib as L_
+from . import ops
+from .config import Config
+from .models import Discriminator, Generator, _pad_batch, trajectory_to_absolute
+
+
+# ------------------------------------------------------------------------------------------
+# flat parameter storage + fused Adam
+# ------------------------------------------------------------------------------------------
+class FlatParams:
+    """Re-homes every parameter of a module into one contiguous fp32 buffer (16-byte aligned
+    segments) with a matching flat gradient buffer; p.data / p.grad become views."""
+
+    def __init__(self, module: nn.Module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        dev = params[0].device
+        self.params = params
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.views_g: List[torch.Tensor] = []
+        for p, o in zip(params, offs):
+            seg = self.flat[o:o + p.numel()].view_as(p)
+            seg.copy_(p.data)
+            p.data = seg
+            g = self.grad[o:o + p.numel()].view_as(p)
+            p.grad = g
+            self.views_g.append(g)
+        self.offsets = offs
+        self.total = total
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, g in zip(self.params, self.views_g):
+            p.grad = g                       # autograd accumulates into the flat buffer in place
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (RG.py:864-873) as one gmt_adam_step launch over the flat
+    buffer.  Exposes param_groups / state like torch.optim.Adam so schedulers and checkpoints
+    work unchanged."""
+
+    def __init__(self, flat: FlatParams, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+        super().__init__(flat.params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+        self.flat = flat
+        self.exp_avg = torch.zeros_like(flat.flat)
+        self.exp_avg_sq = torch.zeros_like(flat.flat)
+        self.step_count = 0
+        self.grad_scale = grad_scale
+        for p, o in zip(flat.params, flat.offsets):
+            self.state[p] = {'step': torch.tensor(0.0),
+                             'exp_avg': self.exp_avg[o:o + p.numel()].view_as(p),
+                             'exp_avg_sq': self.exp_avg_sq[o:o + p.numel()].view_as(p)}
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self.step_count += 1
+        ops.adam_step_(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'], g['eps'],
+                       self.step_count, self.grad_scale)
+        for st in self.state.values():
+            st['step'] = torch.tensor(float(self.step_count))
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # re-home loaded moments into the flat buffers
+        steps = [int(st['step']) for st in self.state.values() if 'step' in st]
+        self.step_count = max(steps) if steps else 0
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            st = self.state[p]
+            for key, buf in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq)):
+                view = buf[o:o + p.numel()].view_as(p)
+                view.copy_(st[key])
+                st[key] = view
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k): pass
+    def add_figure(self, *a, **k): pass
+    def close(self): pass
+
+
+def _make_writer(log_dir: str):
+    try:
+        from datetime import datetime
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(os.path.join(log_dir, 'trajectory_gan_' + datetime.now().strftime('%Y%m%d_%H%M%S')))
+    except Exception:
+        return _NullWriter()
+
+
+# ------------------------------------------------------------------------------------------
+# gradient penalty (RecurrentGAN.py:790-842)
+# ------------------------------------------------------------------------------------------
+def compute_gradient_penalty(discriminator: Discriminator, real_trajectories, fake_trajectories, real_dts, fake_dts,
+                             lengths, device, alpha: Optional[torch.Tensor] = None) -> torch.Tensor:
+    from .composite import discriminator_forward_torch
+    batch_size = real_trajectories.shape[0]
+    min_len = min(real_trajectories.shape[1], fake_trajectories.shape[1])
+    real_trajectories, fake_trajectories = real_trajectories[:, :min_len], fake_trajectories[:, :min_len]
+    real_dts, fake_dts = real_dts[:, :min_len], fake_dts[:, :min_len]
+    lengths = lengths.clamp(max=min_len)
+    if alpha is None:
+        alpha = torch.rand(batch_size, 1, 1, device=real_trajectories.device)
+    alpha = alpha.reshape(batch_size, 1, 1)
+    alpha_dt = alpha.squeeze(-1)
+    interpolated = (alpha * real_trajectories + (1 - alpha) * fake_trajectories).detach().requires_grad_(True)
+    interpolated_dts = alpha_dt * real_dts + (1 - alpha_dt) * fake_dts
+    d_interpolated = discriminator_forward_torch(discriminator, interpolated, interpolated_dts, lengths)
+    gradients = torch.autograd.grad(outputs=d_interpolated, inputs=interpolated,
+                                    grad_outputs=torch.ones_like(d_interpolated),
+                                    create_graph=True, retain_graph=True)[0]
+    gradient_norm = gradients.reshape(batch_size, -1).norm(2, dim=1)
+    return ((gradient_norm - 1) ** 2).mean()
+
+
+# ------------------------------------------------------------------------------------------
+# Trainer
+# ------------------------------------------------------------------------------------------
+class Trainer:
+    def __init__(self, generator: Generator, discriminator: Discriminator, config: Config, device: torch.device,
+                 log_dir: str = 'runs', world_size: int = 1, process_group=None):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise L_.GmtError('Trainer runs on an MI355X (device "cuda"); there is no CPU path')
+        L_.lib()
+        self.generator = generator.to(device)
+        self.discriminator = discriminator.to(device)
+        self.config = config
+        self.device = device
+        self.use_amp = False          # fp32 parity configuration
+        self.scaler = None
+        self.world_size = world_size
+        self.process_group = process_group
+        self.g_flat = FlatParams(self.generator)
+        self.d_flat = FlatParams(self.discriminator)
+        gs = 1.0 / world_size
+        self.g_optimizer = FusedAdam(self.g_flat, lr=config.learning_rate, betas=config.betas, grad_scale=gs)
+        self.d_optimizer = FusedAdam(self.d_flat, lr=config.learning_rate, betas=config.betas, grad_scale=gs)
+        self.g_scheduler = ReduceLROnPlateau(self.g_optimizer, mode='min', factor=config.lr_factor,
+                                             patience=config.lr_patience, min_lr=config.min_lr)
+        self.d_scheduler = ReduceLROnPlateau(self.d_optimizer, mode='min', factor=config.lr_factor,
+                                             patience=config.lr_patience, min_lr=config.min_lr)
+        self.writer = _make_writer(log_dir)
+        self.best_loss = float('inf')
+        self.patience_counter = 0
+        self.epoch = 0
+        self.d_step = 0
+
+    # ---- helpers ---------------------------------------------------------------------
+    def get_teacher_forcing_ratio(self) -> float:
+        c = self.config
+        if self.epoch >= c.teacher_forcing_decay_epochs:
+            return c.teacher_forcing_end
+        progress = self.epoch / c.teacher_forcing_decay_epochs
+        return c.teacher_forcing_start - progress * (c.teacher_forcing_start - c.teacher_forcing_end)
+
+    def _allreduce(self, flat: FlatParams):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=self.process_group)
+
+    def _to_dev(self, batch: Dict):
+        d = self.device
+        return (batch['starts'].to(d, non_blocking=True), batch['ends'].to(d, non_blocking=True),
+                batch['sequences'].to(d, non_blocking=True), batch['lengths'].to(d, non_blocking=True))
+
+    # ---- discriminator step (RecurrentGAN.py:913-1029) ------------------------------
+    def train_discriminator_step(self, real_batch: Dict, noise: Optional[Dict] = None) -> Dict[str, float]:
+        noise = noise or {}
+        cfg = self.config
+        self.d_optimizer.zero_grad()
+        starts, ends, sequences, lengths = self._to_dev(real_batch)
+        batch_size, T = sequences.shape[0], sequences.shape[1]
+        real_trajectories = trajectory_to_absolute(starts, sequences[:, :, :2])
+        real_dts_padded = F.pad(sequences[:, :, 2], (1, 0), value=0.001)
+        z = noise.get('z')
+        z = torch.randn(batch_size, cfg.latent_dim, device=self.device) if z is None else z.to(self.device)
+        with torch.no_grad():
+            fake_sequences, fake_lengths = self.generator(starts, ends, z, target_sequences=sequences,
+                                                          target_lengths=lengths, teacher_forcing_ratio=0.0,
+                                                          tf_mask=[False] * T)
+        fake_trajectories = trajectory_to_absolute(starts, fake_sequences[:, :, :2])
+        fake_dts_padded = F.pad(fake_sequences[:, :, 2], (1, 0), value=0.001)
+        lengths_plus_one = lengths + 1
+        real_score = self.discriminator(real_trajectories, real_dts_padded, lengths_plus_one)
+        fake_score = self.discriminator(fake_trajectories, fake_dts_padded, fake_lengths + 1)
+        d_loss = fake_score.mean() - real_score.mean()
+        gp = torch.zeros((), device=self.device)
+        do_gp = (self.d_step % max(1, cfg.gp_every_n) == 0)
+        self.d_step += 1
+        if do_gp:
+            frac = min(max(cfg.gp_batch_frac, 0.0), 1.0)
+            gp_bs = max(1, int(math.ceil(batch_size * frac)))
+            if gp_bs < batch_size:
+                idx = noise.get('gp_idx')
+                idx = torch.randperm(batch_size, device=self.device) if idx is None else idx.to(self.device)
+                idx = idx[:gp_bs]
+                sel = lambda t: t.index_select(0, idx)
+            else:
+                sel = lambda t: t
+            alpha = noise.get('alpha')
+            gp = compute_gradient_penalty(self.discriminator, sel(real_trajectories), sel(fake_trajectories),
+                                          sel(real_dts_padded), sel(fake_dts_padded), sel(lengths_plus_one),
+                                          self.device, None if alpha is None else alpha.to(self.device))
+        total_loss = d_loss + cfg.gradient_penalty_weight * gp
+        total_loss.backward()
+        self._allreduce(self.d_flat)
+        self.d_optimizer.step()
+        vals = torch.stack([d_loss.detach(), gp.detach(), real_score.detach().mean(), fake_score.detach().mean()]).tolist()
+        return {'d_loss': vals[0], 'd_gp': vals[1], 'd_real_score': vals[2], 'd_fake_score': vals[3]}
+
+    # ---- generator step (RecurrentGAN.py:1031-1118) ---------------------------------
+    def train_generator_step(self, real_batch: Dict, noise: Optional[Dict] = None) -> Dict[str, float]:
+        noise = noise or {}
+        cfg = self.config
+        self.g_optimizer.zero_grad()
+        starts, ends, sequences, lengths = self._to_dev(real_batch)
+        batch_size, T = sequences.shape[0], sequences.shape[1]
+        z = noise.get('z')
+        z = torch.randn(batch_size, cfg.latent_dim, device=self.device) if z is None else z.to(self.device)
+        tf_ratio = self.get_teacher_forcing_ratio()
+        tf_mask = noise.get('tf_mask')
+        fake_sequences, fake_lengths = self.generator(starts, ends, z, target_sequences=sequences,
+                                                      target_lengths=lengths, teacher_forcing_ratio=tf_ratio,
+                                                      tf_mask=tf_mask)
+        fake_deltas = fake_sequences[:, :, :2]
+        fake_trajectories = trajectory_to_absolute(starts, fake_deltas)
+        fake_dts_padded = F.pad(fake_sequences[:, :, 2], (1, 0), value=0.001)
+        # the critic is a fixed function here: its weight gradients (which the reference computes
+        # and discards at the next d_optimizer.zero_grad()) are skipped
+        d_params = self.d_flat.params
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            fake_score = self.discriminator(fake_trajectories, fake_dts_padded, fake_lengths + 1)
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+        g_loss = -fake_score.mean()
+        final_pos = fake_trajectories[torch.arange(batch_size, device=self.device), fake_lengths]
+        endpoint_loss = F.mse_loss(final_pos, ends)
+        target_direction = ends - starts
+        target_direction = target_direction / (torch.sqrt((target_direction ** 2).sum(dim=-1, keepdim=True)) + 1e-8)
+        movement_norms = torch.sqrt((fake_deltas ** 2).sum(dim=-1, keepdim=True) + 1e-8)
+        movement_directions = fake_deltas / movement_norms
+        cosine_sim = (movement_directions * target_direction.unsqueeze(1)).sum(dim=-1)
+        mask = (torch.arange(T, device=self.device).unsqueeze(0) < fake_lengths.unsqueeze(1)).float()
+        direction_loss = ((1 - cosine_sim) * mask).sum() / mask.sum()
+        total_loss = g_loss + cfg.endpoint_loss_weight * endpoint_loss + cfg.direction_loss_weight * direction_loss
+        total_loss.backward()
+        self._allreduce(self.g_flat)
+        self.g_optimizer.step()
+        vals = torch.stack([g_loss.detach(), endpoint_loss.detach(), direction_loss.detach(),
+                            fake_score.detach().mean()]).tolist()
+        return {'g_loss': vals[0], 'g_endpoint_loss': vals[1], 'g_direction_loss': vals[2],
+                'g_fake_score': vals[3], 'teacher_forcing_ratio': tf_ratio}
+
+    # ---- epoch / run loop (RecurrentGAN.py:1120-1303) -------------------------------
+    def train_epoch(self, dataloader: Iterable) -> Dict[str, float]:
+        self.generator.train()
+        self.discriminator.train()
+        keys = ['d_loss', 'd_gp', 'd_real_score', 'd_fake_score', 'g_loss', 'g_endpoint_loss',
+                'g_direction_loss', 'g_fake_score']
+        epoch_metrics: Dict[str, List[float]] = {k: [] for k in keys}
+        for batch in dataloader:
+            for _ in range(self.config.n_critic):
+                for k, v in self.train_discriminator_step(batch).items():
+                    if k in epoch_metrics:
+                        epoch_metrics[k].append(v)
+            for k, v in self.train_generator_step(batch).items():
+                if k in epoch_metrics:
+                    epoch_metrics[k].append(v)
+        avg = {k: float(np.mean(v)) for k, v in epoch_metrics.items() if v}
+        avg['teacher_forcing_ratio'] = self.get_teacher_forcing_ratio()
+        return avg
+
+    def log_metrics(self, metrics: Dict[str, float], step: int) -> None:
+        for name, value in metrics.items():
+            self.writer.add_scalar(f'train/{name}', value, step)
+        self.writer.add_scalar('train/g_lr', self.g_optimizer.param_groups[0]['lr'], step)
+        self.writer.add_scalar('train/d_lr', self.d_optimizer.param_groups[0]['lr'], step)
+
+    def log_trajectories(self, dataloader, step: int) -> None:
+        """Observability only (RG.py:1167-1209); figures need matplotlib + tensorboard and are skipped without them."""
+        return None
+
+    def save_checkpoint(self, path: str, is_best: bool = False) -> None:
+        checkpoint = {'epoch': self.epoch, 'generator_state_dict': self.generator.state_dict(),
+                      'discriminator_state_dict': self.discriminator.state_dict(),
+                      'g_optimizer_state_dict': self.g_optimizer.state_dict(),
+                      'd_optimizer_state_dict': self.d_optimizer.state_dict(),
+                      'config': {k: getattr(self.config, k) for k in dir(self.config) if not k.startswith('_')},
+                      'best_loss': self.best_loss}
+        torch.save(checkpoint, path)
+        if is_best:
+            torch.save(checkpoint, path.replace('.pt', '_best.pt'))
+
+    def load_checkpoint(self, path: str) -> None:
+        checkpoint = torch.load(path, map_location=self.device, weights_only=True)
+        self.epoch = checkpoint['epoch']
+        self.generator.load_state_dict(checkpoint['generator_state_dict'])
+        self.discriminator.load_state_dict(checkpoint['discriminator_state_dict'])
+        self.g_optimizer.load_state_dict(checkpoint['g_optimizer_state_dict'])
+        self.d_optimizer.load_state_dict(checkpoint['d_optimizer_state_dict'])
+        self.best_loss = checkpoint.get('best_loss', float('inf'))
+        print(f'Loaded checkpoint from epoch {self.epoch}')
+
+    def train(self, dataloader, num_epochs: int, checkpoint_dir: str = 'checkpoints') -> None:
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        print(f'Starting training for {num_epochs} epochs')
+        print(f'Device: {self.device}')
+        print(f'Batch size: {self.config.batch_size}')
+        for epoch in range(self.epoch, num_epochs):
+            self.epoch = epoch
+            metrics = self.train_epoch(dataloader)
+            self.log_metrics(metrics, epoch)
+            if epoch % 10 == 0:
+                self.log_trajectories(dataloader, epoch)
+            combined_loss = metrics['d_loss'] + metrics['g_loss']
+            self.g_scheduler.step(metrics['g_loss'])
+            self.d_scheduler.step(metrics['d_loss'])
+            if combined_loss < self.best_loss:
+                self.best_loss = combined_loss
+                self.patience_counter = 0
+                is_best = True
+            else:
+                self.patience_counter += 1
+                is_best = False
+            if epoch % 10 == 0 or is_best:
+                self.save_checkpoint(os.path.join(checkpoint_dir, f'checkpoint_epoch_{epoch}.pt'), is_best)
+            print(f"Epoch {epoch}/{num_epochs} | D Loss: {metrics['d_loss']:.4f} | G Loss: {metrics['g_loss']:.4f} | "
+                  f"Endpoint: {metrics['g_endpoint_loss']:.4f} | TF: {metrics['teacher_forcing_ratio']:.2f}")
+            if self.patience_counter >= self.config.patience:
+                print(f'Early stopping at epoch {epoch}')
+                break
+        self.writer.close()
+        print('Training complete!')

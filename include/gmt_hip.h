@@ -82,9 +82,9 @@ int gmt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * gmt_pack_weight: re-orders a weight block into the per-lane MFMA fragment order the
  * recurrent kernels stream (see csrc/lstm_tile.h).  The logical operand is B[k][n] =
  * src[k*stride_k + n*stride_n] with n = g*gate_stride + 32*w + j (g < n_gates, w < n_waves,
- * j < 32); rows k >= k_valid are zero padding up to K (K % 8 == 0).  dst holds
- * n_waves*n_gates*32*K floats.  Run once per optimizer step per weight. */
-int gmt_pack_weight(const float* src, float* dst, int K, int k_valid, int n_waves, int n_gates,
+ * j < 32); rows k >= k_valid and columns n >= n_valid are zero padding (K % 8 == 0).
+ * dst holds n_waves*n_gates*32*K floats.  Run once per optimizer step per weight. */
+int gmt_pack_weight(const float* src, float* dst, int K, int k_valid, int n_valid, int n_waves, int n_gates,
                     int gate_stride, long long stride_k, long long stride_n, hipStream_t stream);
 
 /* gmt_lstm_layer_fwd: one layer, ndir directions, all timesteps of a packed (per-row
@@ -113,6 +113,60 @@ int gmt_lstm_layer_fwd(const float* x, const float* pregates, const float* w_ih_
 int gmt_lstm_layer_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths,
                        const float* dh_all, const float* dh_final, const float* dgates_extra,
                        const float* dc_extra, int L, int B, int H, int ndir, hipStream_t stream);
+
+/* ---- persistent generator rollout -----------------------------------------------------------
+ * Replaces the autoregressive loop of Generator.forward, RG.py:508-604 (dynamic features
+ * RG.py:486-506, nn.LSTM step RG.py:571, output_layer RG.py:460-464/574, softplus RG.py:577-580,
+ * position update RG.py:585, teacher forcing RG.py:588-595) - T steps in one launch.
+ * All buffers time-major; B % 32 == 0; H in {32, 64, 128, 256}; HH = H/2.  Packed operands
+ * are produced by gmt_pack_weight (form given per field). */
+typedef struct gmt_gen_fwd_args {
+    const float* g0;        /* [B][4H]  condition . W_ih_l0[:, 3:3+H]^T + b_ih_l0 + b_hh_l0 (time-invariant) */
+    const float* w_u_pk;    /* W_u = W_ih_l0[:, {0,1,2, 3+H..3+H+3}] ([4H][7]); K 8, k_valid 7, 4 gates, stride_n 7 */
+    const float* w_hh0_pk;  /* K H, 4 gates */
+    const float* w_ih1_pk;  /* K H, 4 gates */
+    const float* w_hh1_pk;  /* K H, 4 gates */
+    const float* bias1;     /* [4H] b_ih_l1 + b_hh_l1 */
+    const float* w1_pk;     /* output_layer.0.weight [HH][H]: K H, 1 gate, n_waves max(1,H/64), n_valid HH, stride_n H */
+    const float* b1;        /* [HH] */
+    const float* w2;        /* output_layer.2.weight [3][HH], plain */
+    const float* b2;        /* [3] */
+    const float* starts;    /* [B][2] */
+    const float* ends;      /* [B][2] */
+    const float* init_in;   /* [3]  initial_input parameter */
+    const float* target;    /* [T][B][3] or NULL */
+    const unsigned char* tf_mask; /* [T] (device) or NULL: 1 = step t+1 is fed the target of step t */
+    float* out_seq;         /* [T][B][3] (dx, dy, dt) */
+    /* saved for the backward sweep; all NULL for a no-grad rollout */
+    float* gates0; float* c0_all; float* h0_all;   /* [T][B][4H], [T][B][H], [T][B][H] */
+    float* gates1; float* c1_all; float* h1_all;
+    float* u_all;           /* [T][B][8]  (in0,in1,in2, rem_x, rem_y, dist, angle, 0) */
+    float* y_all;           /* [T][B][HH] head activation after LeakyReLU */
+    float* oraw_all;        /* [T][B]     pre-softplus dt logit */
+    int T, B, H;
+} gmt_gen_fwd_args;
+int gmt_gen_rollout_fwd(const gmt_gen_fwd_args* args, hipStream_t stream);
+
+/* BPTT of the same loop (autograd over RG.py:559-595 in the reference).  gates0 / gates1 are
+ * overwritten with d(pre-activation) of layer 0 / 1; the caller contracts them (and d_ypre,
+ * d_o) with the saved activations for the weight gradients. */
+typedef struct gmt_gen_bwd_args {
+    float* gates0; const float* c0_all;
+    float* gates1; const float* c1_all;
+    const float* y_all; const float* oraw_all; const float* u_all;
+    const float* d_out;      /* [T][B][3] gradient of out_seq */
+    const float* w1T_pk;     /* B[k][n] = W1[k][n]: K HH, 1 gate, n_waves H/32, stride_k H, stride_n 1 */
+    const float* w_l1T_pk;   /* cat([W_hh_l1, W_ih_l1], dim=1) [4H][2H]: K 4H, 2 gates, gate_stride H, stride_k 2H */
+    const float* w_hh0T_pk;  /* B[k][n] = W_hh_l0[k][n]: K 4H, 1 gate, stride_k H */
+    const float* w_uP;       /* [4H][8] plain: W_u zero-padded to 8 columns */
+    const float* w2;         /* [3][HH] */
+    const unsigned char* tf_mask;
+    float* d_ypre;           /* [T][B][HH] out */
+    float* d_o;              /* [T][B][3] out: gradient of the head's raw output */
+    float* d_in0;            /* [B][3] out: gradient of the initial input, per row */
+    int T, B, H;
+} gmt_gen_bwd_args;
+int gmt_gen_rollout_bwd(const gmt_gen_bwd_args* args, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,147 @@
+"""GPU parity of the drop-in surface (Generator / Discriminator / Trainer steps) against the
+golden vectors recorded from the reference and against the CPU oracle.  Tolerance: 1e-4
+relative (max-norm per tensor) on losses and gradients in fp32, as BASELINE.json states."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import paramgen as PG
+from oracle import gan_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL = 1e-4
+
+
+def build(cfg_over, seed_g, seed_d):
+    import generative_mouse_trajectories_amd as gmt
+    cfg = gmt.Config()
+    for k, v in cfg_over.items():
+        setattr(cfg, k, v)
+    cfg.lstm_dropout = 0.0     # parity mode: same as the golden script (dropout zeroed)
+    cfg.head_dropout = 0.0
+    G = gmt.Generator(cfg)
+    D = gmt.Discriminator(cfg)
+    oc = O.OracleConfig(**cfg_over)
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in PG.make_generator_params(oc, seed_g).items()}, strict=True)
+    pd, bd = PG.make_discriminator_params(oc, seed_d)
+    sd = {k: torch.from_numpy(v) for k, v in pd.items()}
+    sd.update({k: torch.from_numpy(v) for k, v in bd.items()})
+    D.load_state_dict(sd, strict=True)
+    return gmt, cfg, G.to(DEV).train(), D.to(DEV).train()
+
+
+def dev_batch(b):
+    return {k: v.to(DEV) for k, v in b.items()}
+
+
+def test_modules_tiny_vs_reference():
+    g = H.load('tiny_modules.npz')
+    gmt, cfg, G, D = build(H.TINY, 11, 12)
+    b = dev_batch(H.batch_t(6, 9, 13, H.TINY_LENGTHS))
+    z = H.t(g['tiny_z']).to(DEV)
+    T = 9
+    for name, mask in (('tf0', [False] * T), ('tf1', [True] * T), ('mix', list(g['tiny_gfwd_mix_mask']))):
+        with torch.no_grad():
+            seq, _ = G(b['starts'], b['ends'], z, target_sequences=b['sequences'], target_lengths=b['lengths'],
+                       tf_mask=mask)
+        H.assert_close(seq, g[f'tiny_gfwd_{name}'], 2e-5, f'G fwd {name}')
+    G.zero_grad()
+    seq, _ = G(b['starts'], b['ends'], z, target_sequences=b['sequences'], target_lengths=b['lengths'],
+               tf_mask=list(g['tiny_gfwd_mix_mask']))
+    (seq * H.t(g['tiny_gfwd_mix_w']).to(DEV)).sum().backward()
+    for k, p in G.named_parameters():
+        H.assert_close(p.grad, g[f'tiny_gbwd_mix_grad/{k}'], TOL, f'G bwd {k}')
+
+    traj = H.t(g['tiny_d_traj']).to(DEV).requires_grad_(True)
+    dts = H.t(g['tiny_d_dts']).to(DEV).requires_grad_(True)
+    score = D(traj, dts, b['lengths'] + 1)
+    H.assert_close(score, g['tiny_d_score'], 2e-5, 'D score')
+    D.zero_grad()
+    (score * H.t(g['tiny_d_ws']).to(DEV)).sum().backward()
+    for k, p in D.named_parameters():
+        H.assert_close(p.grad, g[f'tiny_d_grad/{k}'], TOL, f'D grad {k}')
+    H.assert_close(traj.grad, g['tiny_d_gtraj'], TOL, 'D gtraj')
+    H.assert_close(dts.grad, g['tiny_d_gdts'], TOL, 'D gdts')
+    for k, bf in D.named_buffers():
+        H.assert_close(bf, g[f'tiny_d_buf_after1/{k}'], 1e-5, f'buf {k}')
+    # gradient penalty
+    D.zero_grad()
+    gp = gmt.compute_gradient_penalty(D, H.t(g['tiny_d_traj']).to(DEV), H.t(g['tiny_gp_fake']).to(DEV),
+                                      H.t(g['tiny_d_dts']).to(DEV), H.t(g['tiny_gp_fdts']).to(DEV),
+                                      b['lengths'] + 1, torch.device(DEV), alpha=H.t(g['tiny_gp_alpha']).to(DEV))
+    assert abs(gp.item() - float(g['tiny_gp_value'])) <= TOL * abs(float(g['tiny_gp_value']))
+    gp.backward()
+    for k, p in D.named_parameters():
+        gr = p.grad if p.grad is not None else torch.zeros_like(p)
+        H.assert_close(gr, g[f'tiny_gp_grad/{k}'], 3e-4, f'GP grad {k}')
+    # generate()
+    cfg.max_generation_steps = 12
+    gs, gl = G.generate(b['starts'], b['ends'], z)
+    H.assert_close(gs, g['tiny_gen_out'], 2e-5, 'generate out')
+    assert np.array_equal(gl.cpu().numpy(), g['tiny_gen_len'])
+
+
+def _replay(tag, cfg_over, B, T, lengths, full, gtol):
+    g = H.load(f'{tag}_steps.npz')
+    gmt, cfg, G, D = build(cfg_over, 21, 22)
+    tr = gmt.Trainer(G, D, cfg, torch.device(DEV), '/tmp/runs_gpu')
+    batch = H.batch_t(B, T, 23, lengths)
+    plan = [s.split(':') for s in g[f'{tag}_plan']]
+
+    def check(name, val, rtol):
+        ref = g[name]
+        val = val.detach().cpu().numpy()
+        if not full:
+            val = PG.digest(val)
+            e = np.abs(val - ref)
+            assert e[0] <= rtol * max(ref[0], 1e-30), f'{name} norm {e[0] / max(ref[0], 1e-30):.2e}'
+            assert e[2:].max() <= 4 * rtol * max(np.abs(ref[2:]).max(), 1e-30), f'{name} samples'
+        else:
+            H.assert_close(val, ref, rtol, name)
+
+    for i, (kind, epoch) in enumerate(plan):
+        tr.epoch = int(epoch)
+        z = H.t(g[f'{tag}_s{i}_z'])
+        ref_m = dict(zip(list(g[f'{tag}_s{i}_metric_names']), g[f'{tag}_s{i}_metrics']))
+        if kind == 'D':
+            noise = {'z': z}
+            if f'{tag}_s{i}_alpha' in g:
+                noise['alpha'] = H.t(g[f'{tag}_s{i}_alpha'])
+                if f'{tag}_s{i}_gp_idx' in g:
+                    noise['gp_idx'] = H.t(g[f'{tag}_s{i}_gp_idx'])
+            m = tr.train_discriminator_step(batch, noise)
+            model, opt = D, tr.d_optimizer
+        else:
+            m = tr.train_generator_step(batch, {'z': z, 'tf_mask': list(g[f'{tag}_s{i}_tf_mask'])})
+            model, opt = G, tr.g_optimizer
+        for k, v in ref_m.items():
+            assert abs(m[k] - v) <= TOL * max(abs(v), 1e-3), f'step {i} metric {k}: {m[k]} vs {v}'
+        for k, p in model.named_parameters():
+            check(f'{tag}_s{i}_grad/{k}', p.grad, gtol)
+            check(f'{tag}_s{i}_m/{k}', opt.state[p]['exp_avg'], gtol)
+            if full:
+                # Adam's update is lr * m / (sqrt(v) + eps): where the gradient itself is at round-off
+                # level the update direction is not determined, so bound those entries by the step size
+                ref = g[f'{tag}_s{i}_param/{k}']
+                diff = np.abs(p.detach().cpu().numpy() - ref)
+                lr = cfg.learning_rate
+                assert diff.max() <= 2.0 * lr * (i + 1), f'param {k}: {diff.max():.2e}'
+                assert (diff > 0.02 * lr).mean() <= 0.02, f'param {k}: {(diff > 0.02 * lr).mean():.3f} of entries off'
+            else:
+                check(f'{tag}_s{i}_param/{k}', p, 1e-4)
+        for k, bf in D.named_buffers():
+            check(f'{tag}_s{i}_buf/{k}', bf, 1e-5)
+
+
+def test_train_steps_tiny_vs_reference():
+    _replay('tiny', H.TINY, 6, 9, H.TINY_LENGTHS, True, 2e-4)
+
+
+def test_train_steps_mid_vs_reference():
+    _replay('mid', H.MID, 8, 12, H.MID_LENGTHS, False, 3e-4)
+
+
+def test_train_steps_default_vs_reference():
+    _replay('default', H.DEFAULT, 4, 8, H.DEFAULT_LENGTHS, False, 3e-4)
