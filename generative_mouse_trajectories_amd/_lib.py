@@ -46,7 +46,8 @@ _SIGS = {
     'gmt_adam_step': [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_f, c_p],
     'gmt_pack_weight': [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_p],
     'gmt_lstm_layer_fwd': [c_p] * 10 + [c_i] * 5 + [c_p],
-    'gmt_lstm_layer_bwd': [c_p] * 8 + [c_i] * 4 + [c_p],
+    'gmt_lstm_layer_bwd': [c_p] * 11 + [c_i] * 4 + [c_p],
+    'gmt_lstm_layer_bwd2': [c_p] * 12 + [c_i] * 5 + [c_p],
     'gmt_gen_rollout_fwd': [c_p, c_p],
     'gmt_gen_rollout_bwd': [c_p, c_p],
 }
@@ -90,8 +91,38 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def call(name, *args):
-    rc = getattr(lib(), name)(*args)
+# Optional per-kernel timing with events recorded on the launch stream (bench.py turns it
+# on for the timed region: roofline.achieved needs the dominant kernel's own duration).
+PROFILE = None      # None, or dict: label -> list of (start_event, end_event)
+
+
+def profile_start():
+    global PROFILE
+    PROFILE = {}
+
+
+def profile_stop():
+    """Returns {label: (launches, total_ms)}; call after the stream has been synchronised."""
+    global PROFILE
+    out = {}
+    if PROFILE:
+        for k, evs in PROFILE.items():
+            out[k] = (len(evs), sum(a.elapsed_time(b) for a, b in evs))
+    PROFILE = None
+    return out
+
+
+def call(name, *args, label=None):
+    fn = getattr(lib(), name)
+    if PROFILE is not None:
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        PROFILE.setdefault(label or name, []).append((a, b))
+    else:
+        rc = fn(*args)
     if rc != 0:
         raise GmtError(f'{name} failed: {ERRORS.get(rc, rc)}')
 

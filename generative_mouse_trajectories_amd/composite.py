@@ -77,3 +77,28 @@ def discriminator_forward_torch(D, trajectories: torch.Tensor, dts: torch.Tensor
         if l + 1 < nl and D.training and cfg.lstm_dropout > 0:
             x = F.dropout(x, cfg.lstm_dropout, True)
     return D.output_layers(torch.cat([hf, hb], dim=-1))
+
+
+def discriminator_forward_gp(D, trajectories: torch.Tensor, dts: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+    """Twice-differentiable discriminator forward for the gradient penalty: the BiLSTM runs in
+    the HIP kernels (ops.LSTMLayerGPFn: forward, first backward and the second-order sweep
+    are each one persistent launch per layer); the cheap non-recurrent pieces (kinematic
+    features, spectral-norm linears) are torch ops, which autograd differentiates twice."""
+    from . import ops
+    from .models import _pad_batch
+    L_.require_cuda(trajectories, dts)
+    cfg = D.config
+    B = trajectories.shape[0]
+    Bp = ops.pad_rows(B)
+    pos = _pad_batch(trajectories.transpose(0, 1), Bp, 1)
+    d = _pad_batch(dts.transpose(0, 1), Bp, 1)
+    lens = _pad_batch(lengths.to(device=trajectories.device, dtype=torch.int32).clamp(min=1), Bp, 0, 1).contiguous()
+    x = D.feature_encoder(kinematics_torch(pos, d))
+    nl = cfg.discriminator_num_layers
+    h_final = None
+    for l in range(nl):
+        h_all, h_final, _, _ = ops.LSTMLayerGPFn.apply(x.contiguous(), lens, *D.lstm.layer_weights(l))
+        x = h_all
+        if l + 1 < nl and D.training and cfg.lstm_dropout > 0:
+            x = F.dropout(x, cfg.lstm_dropout, True)
+    return D.output_layers(h_final[:B])

@@ -1,0 +1,233 @@
+// Second-order ("double backward") sweep of the packed BiLSTM layer, needed by the WGAN-GP
+// gradient penalty - compute_gradient_penalty, RecurrentGAN.py:790-842, where
+// torch.autograd.grad(..., create_graph=True) differentiates THROUGH the LSTM's backward.
+//
+// The first backward sweep B (lstm_bwd_kernel) maps (dY, dh_final; i,f,g,o,c; W) -> dX.
+// Given xhat = adjoint of dX this kernel computes the adjoints of B's inputs:
+//   hhat_all  = adjoint of dY            (also the xhat of the layer above)
+//   hhat_final= adjoint of dh_final
+//   g_gates   = adjoint of the saved activated gates i,f,g,o
+//   g_c       = adjoint of the saved cell states
+// (the weight adjoints are GEMMs over the saved da / xhat / hhat buffers, done by the host).
+// B is linear in dY, so its adjoint is a forward-in-time recurrence with exactly the shape
+// of the forward layer:  ahat_t = xhat_t W_ih^T + hhat_{t-1} W_hh^T  (same fragment-major
+// weights, W_hh resident in registers), followed by an element-wise second-derivative
+// block.  Same workgroup / wave / MFMA decomposition as lstm_fwd_kernel (lstm_tile.h).
+#include "lstm_tile.h"
+
+namespace {
+
+template <int NW, bool RES, int IX>
+__global__ __launch_bounds__(NW * 64, 1)
+void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ w_ih_pk,
+                      const float* __restrict__ w_hh_pk, const int* __restrict__ lengths,
+                      const float* __restrict__ gates, const float* __restrict__ c_all,
+                      const float* __restrict__ dct_all, const float* __restrict__ dht_all,
+                      float* __restrict__ hhat_all, float* __restrict__ hhat_final,
+                      float* __restrict__ g_gates, float* __restrict__ g_c,
+                      int L, int B, int ndir, int n_tiles)
+{
+    constexpr int H = NW * 32;
+    constexpr int KS = H / 2;
+    constexpr int I = IX * H;
+    constexpr int NT = NW * 64;
+    extern __shared__ float smem[];
+    float* hT = smem;                                  // [2][H][LDA]  hhat state
+    float* xT = smem + 2 * H * GMT_LDA;                // [2][I][LDA]
+    __shared__ int s_len[GMT_TM];
+    __shared__ int s_maxlen;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.x / n_tiles;
+    const int row0 = (blockIdx.x % n_tiles) * GMT_TM;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int col = wave * 32 + lo;
+
+    if (tid == 0) s_maxlen = 0;
+    __syncthreads();
+    if (tid < GMT_TM) {
+        int ln = lengths ? lengths[row0 + tid] : L;
+        ln = ln < 1 ? 1 : (ln > L ? L : ln);
+        s_len[tid] = ln;
+        atomicMax(&s_maxlen, ln);
+    }
+    for (int i = tid; i < 2 * H * GMT_LDA; i += NT) hT[i] = 0.0f;
+    __syncthreads();
+    const int tmax = s_maxlen;
+
+    const float4* whh = reinterpret_cast<const float4*>(w_hh_pk) + ((size_t)dir * NW + wave) * (H / 8) * 4 * 64;
+    const float4* wih = reinterpret_cast<const float4*>(w_ih_pk) + ((size_t)dir * NW + wave) * (I / 8) * 4 * 64;
+    float wr[4][RES ? KS : 1];
+    if constexpr (RES) gmt_load_resident<4, KS>(wr, whh, lane);
+
+    float chat[16];                                    // adjoint of the incoming cell adjoint (carried)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) chat[r] = 0.f;
+
+    constexpr int XQ = I / 4;
+    constexpr int XS = (GMT_TM * XQ) / NT;
+    float4 xs[XS];
+    auto x_load = [&](int t) {
+        const float4* src = reinterpret_cast<const float4*>(xhat + ((size_t)t * B + row0) * I);
+#pragma unroll
+        for (int j = 0; j < XS; ++j) xs[j] = src[tid + j * NT];
+    };
+    auto x_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < XS; ++j) {
+            const int it = tid + j * NT;
+            const int rr = it / XQ, c4 = it % XQ;
+            float* d = xT + ((size_t)buf * I + 4 * c4) * GMT_LDA + rr;
+            d[0] = xs[j].x; d[GMT_LDA] = xs[j].y; d[2 * GMT_LDA] = xs[j].z; d[3 * GMT_LDA] = xs[j].w;
+        }
+    };
+
+    int cur = 0;
+    if (tmax > 0) { x_load(dir ? tmax - 1 : 0); x_store(0); }
+    __syncthreads();
+
+    const size_t lane_row = (size_t)row0 + 4 * hi;
+    for (int step = 0; step < tmax; ++step) {
+        const int t = dir ? (tmax - 1 - step) : step;
+        const int tp = dir ? t + 1 : t - 1;            // step visited just before t by this sweep
+        const size_t rs = ((size_t)dir * L + t) * B + lane_row;
+        const size_t rsp = ((size_t)dir * L + (tp < 0 ? 0 : (tp >= L ? L - 1 : tp))) * B + lane_row;
+        f32x16 acc[4];
+        if (step + 1 < tmax) x_load(dir ? t - 1 : t + 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        gmt_mma_stream<4>(acc, xT + (size_t)cur * I * GMT_LDA, wih, I, lane);
+        if constexpr (RES) gmt_mma_resident<4, KS>(acc, hT + (size_t)cur * H * GMT_LDA, wr, lane);
+        else gmt_mma_stream<4>(acc, hT + (size_t)cur * H * GMT_LDA, whh, H, lane);
+
+        const float* ho = hT + (size_t)cur * H * GMT_LDA + col * GMT_LDA + 4 * hi;
+        float* hn = hT + (size_t)(cur ^ 1) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
+        const float* gp = gates + rs * (4 * H) + col;
+        const float* cn_p = c_all + rs * H + col;
+        const float* cp_p = c_all + rsp * H + col;
+        const float* dct_p = dct_all + rs * H + col;
+        const float* dht_p = dht_all + rs * H + col;
+        float* gg_p = g_gates + rs * (4 * H) + col;
+        float* gc_p = g_c + rs * H + col;
+        float* gcp_p = g_c + rsp * H + col;
+        float* hh_p = hhat_all ? hhat_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col : nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2);
+            const int ln = s_len[mr + 4 * hi];
+            const bool act = t < ln;
+            float o_gi = 0.f, o_gf = 0.f, o_gg = 0.f, o_go = 0.f, o_gc = 0.f, o_hh = 0.f;
+            float hnew = ho[mr];
+            if (act) {
+                const float* q = gp + (size_t)mr * (4 * H);
+                const float ig = q[0], fg = q[H], gg = q[2 * H], og = q[3 * H];
+                const float cn = cn_p[(size_t)mr * H];
+                const bool has_prev = dir ? (tp < ln) : (tp >= 0);
+                const float cp = has_prev ? cp_p[(size_t)mr * H] : 0.f;
+                const float dct = dct_p[(size_t)mr * H], dht = dht_p[(size_t)mr * H];
+                const float tc = gmt_tanh(cn);
+                const float omt = 1.f - tc * tc;
+                // intermediates of the first backward sweep
+                const float di = dct * gg, dg = dct * ig, df = dct * cp, dov = dht * tc;
+                const float a_i = acc[0][r], a_f = acc[1][r], a_g = acc[2][r], a_o = acc[3][r];
+                const float adi = a_i * ig * (1.f - ig);
+                const float adf = a_f * fg * (1.f - fg);
+                const float adg = a_g * (1.f - gg * gg);
+                const float ado = a_o * og * (1.f - og);
+                const float cprev_hat = chat[r];
+                const float adct = adi * gg + adg * ig + adf * cp + cprev_hat * fg;
+                o_gi = a_i * di * (1.f - 2.f * ig) + adg * dct;
+                o_gf = a_f * df * (1.f - 2.f * fg) + cprev_hat * dct;
+                o_gg = a_g * dg * (-2.f * gg) + adi * dct;
+                o_go = a_o * dov * (1.f - 2.f * og) + adct * dht * omt;
+                const float atc = adct * dht * og * (-2.f * tc) + ado * dht;
+                o_gc = atc * omt;
+                chat[r] = adct;
+                hnew = adct * og * omt + ado * tc;
+                o_hh = hnew;
+                if (has_prev) gcp_p[(size_t)mr * H] += adf * dct;      // c_{prev} also enters df of this step
+            }
+            hn[mr] = hnew;
+            float* w = gg_p + (size_t)mr * (4 * H);
+            w[0] = o_gi; w[H] = o_gf; w[2 * H] = o_gg; w[3 * H] = o_go;
+            gc_p[(size_t)mr * H] = o_gc;
+            if (hh_p) hh_p[(size_t)mr * (ndir * H)] = o_hh;
+        }
+        if (step + 1 < tmax) x_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // padded tail of the tile
+    for (int t = tmax; t < L; ++t) {
+        const size_t rs = ((size_t)dir * L + t) * B + lane_row;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2);
+            float* w = g_gates + (rs + mr) * (4 * H) + col;
+            w[0] = 0.f; w[H] = 0.f; w[2 * H] = 0.f; w[3 * H] = 0.f;
+            g_c[(rs + mr) * H + col] = 0.f;
+            if (hhat_all) hhat_all[((size_t)t * B + lane_row + mr) * (ndir * H) + dir * H + col] = 0.f;
+        }
+    }
+    if (hhat_final) {
+        const float* hl = hT + (size_t)cur * H * GMT_LDA + col * GMT_LDA + 4 * hi;
+        float* hf = hhat_final + lane_row * (ndir * H) + dir * H + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2);
+            hf[(size_t)mr * (ndir * H)] = hl[mr];
+        }
+    }
+}
+
+template <int NW>
+int launch_bwd2(const float* xhat, const float* w_ih_pk, const float* w_hh_pk, const int* lengths, const float* gates,
+                const float* c_all, const float* dct_all, const float* dht_all, float* hhat_all, float* hhat_final,
+                float* g_gates, float* g_c, int L, int B, int I, int ndir, hipStream_t stream)
+{
+    constexpr int H = NW * 32;
+    constexpr bool RES = (NW <= 4);
+    const int n_tiles = B / GMT_TM;
+    const dim3 grid(n_tiles * ndir), block(NW * 64);
+#define GMT_GO(IXV)                                                                                               \
+    {                                                                                                             \
+        const size_t lds = (size_t)(2 * H + 2 * IXV * H) * GMT_LDA * sizeof(float);                               \
+        if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;                                                   \
+        auto k = lstm_bwd2_kernel<NW, RES, IXV>;                                                                  \
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return GMT_ERR_HIP;                                                                                   \
+        hipLaunchKernelGGL(k, grid, block, lds, stream, xhat, w_ih_pk, w_hh_pk, lengths, gates, c_all, dct_all,   \
+                           dht_all, hhat_all, hhat_final, g_gates, g_c, L, B, ndir, n_tiles);                     \
+    }
+    if (I == H) GMT_GO(1)
+    else if (I == 2 * H) GMT_GO(2)
+    else return GMT_ERR_UNSUPPORTED;
+#undef GMT_GO
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+}  // namespace
+
+extern "C" int gmt_lstm_layer_bwd2(const float* xhat, const float* w_ih_pk, const float* w_hh_pk, const int* lengths,
+                                   const float* gates, const float* c_all, const float* dct_all, const float* dht_all,
+                                   float* hhat_all, float* hhat_final, float* g_gates, float* g_c,
+                                   int L, int B, int I, int H, int ndir, hipStream_t stream)
+{
+    GMT_CHECK_ARG(xhat && w_ih_pk && w_hh_pk && gates && c_all && dct_all && dht_all && g_gates && g_c);
+    GMT_CHECK_ARG(L >= 1 && B >= GMT_TM && (B % GMT_TM) == 0 && (ndir == 1 || ndir == 2));
+    switch (H) {
+        case 32: return launch_bwd2<1>(xhat, w_ih_pk, w_hh_pk, lengths, gates, c_all, dct_all, dht_all, hhat_all,
+                                       hhat_final, g_gates, g_c, L, B, I, ndir, stream);
+        case 64: return launch_bwd2<2>(xhat, w_ih_pk, w_hh_pk, lengths, gates, c_all, dct_all, dht_all, hhat_all,
+                                       hhat_final, g_gates, g_c, L, B, I, ndir, stream);
+        case 128: return launch_bwd2<4>(xhat, w_ih_pk, w_hh_pk, lengths, gates, c_all, dct_all, dht_all, hhat_all,
+                                        hhat_final, g_gates, g_c, L, B, I, ndir, stream);
+        case 256: return launch_bwd2<8>(xhat, w_ih_pk, w_hh_pk, lengths, gates, c_all, dct_all, dht_all, hhat_all,
+                                        hhat_final, g_gates, g_c, L, B, I, ndir, stream);
+        default: return GMT_ERR_UNSUPPORTED;
+    }
+}

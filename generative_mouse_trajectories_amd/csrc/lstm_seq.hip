@@ -205,6 +205,9 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
                      const float* __restrict__ dh_final /* [B][ndir*H] or null */,
                      const float* __restrict__ dgates_extra /* [ndir][L][B][4H] or null: extra adjoint of the activated gates */,
                      const float* __restrict__ dc_extra /* [ndir][L][B][H] or null */,
+                     float* __restrict__ da_out /* null: overwrite `gates` in place */,
+                     float* __restrict__ dct_out /* [ndir][L][B][H] or null: total cell adjoint (double backward) */,
+                     float* __restrict__ dht_out /* [ndir][L][B][H] or null: total hidden adjoint (double backward) */,
                      int L, int B, int ndir, int n_tiles)
 {
     constexpr int H = NW * 32;
@@ -252,6 +255,9 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
         const int tp = dir ? t + 1 : t - 1;            // the step the forward pass visited before t
         const size_t rs = ((size_t)dir * L + t) * B + lane_row;
         float* gp = gates + rs * (4 * H) + col;
+        float* wp = (da_out ? da_out : gates) + rs * (4 * H) + col;
+        float* dct_p = dct_out ? dct_out + rs * H + col : nullptr;
+        float* dht_p = dht_out ? dht_out + rs * H + col : nullptr;
         const float* cn_p = c_all + rs * H + col;
         const float* cp_p = c_all + (((size_t)dir * L + (tp < 0 ? 0 : tp)) * B + lane_row) * H + col;
         const float* dy_p = dh_all ? dh_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col : nullptr;
@@ -264,7 +270,7 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
             const int m = mr + 4 * hi;
             const int ln = s_len[m];
             const bool act = t < ln;
-            float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
+            float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f, dct_s = 0.f, dht_s = 0.f;
             float* q = gp + (size_t)mr * (4 * H);
             if (act) {
                 const float ig = q[0], fg = q[H], gg = q[2 * H], og = q[3 * H];
@@ -283,6 +289,7 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
                     dig += ep[0]; dfg += ep[H]; dgg += ep[2 * H]; dog += ep[3 * H];
                 }
                 dc[r] = dct * fg;
+                dct_s = dct; dht_s = dht;
                 dai = dig * ig * (1.f - ig);
                 daf = dfg * fg * (1.f - fg);
                 dag = dgg * (1.f - gg * gg);
@@ -292,7 +299,10 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
                 acc[0][r] = dh[r];                     // frozen row: state passes through
             }
             // d(pre-activation) replaces the gates (zero at padded steps: the weight-gradient GEMM reads it)
-            q[0] = dai; q[H] = daf; q[2 * H] = dag; q[3 * H] = dao;
+            float* w = wp + (size_t)mr * (4 * H);
+            w[0] = dai; w[H] = daf; w[2 * H] = dag; w[3 * H] = dao;
+            if (dct_p) dct_p[(size_t)mr * H] = dct_s;
+            if (dht_p) dht_p[(size_t)mr * H] = dht_s;
             daT[(0 * H + col) * GMT_LDA + m] = dai;
             daT[(1 * H + col) * GMT_LDA + m] = daf;
             daT[(2 * H + col) * GMT_LDA + m] = dag;
@@ -307,7 +317,7 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
     }
     // steps [tmax, L) of the tile are padding: zero their d(pre-activation)
     for (int t = tmax; t < L; ++t) {
-        float* gp = gates + (((size_t)dir * L + t) * B + lane_row) * (4 * H) + col;
+        float* gp = (da_out ? da_out : gates) + (((size_t)dir * L + t) * B + lane_row) * (4 * H) + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float* q = gp + (size_t)((r & 3) + 8 * (r >> 2)) * (4 * H);
@@ -347,7 +357,7 @@ int launch_fwd(const float* x, const float* pregates, const float* w_ih_pk, cons
 template <int NW>
 int launch_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths, const float* dh_all,
                const float* dh_final, const float* dgates_extra, const float* dc_extra,
-               int L, int B, int ndir, hipStream_t stream)
+               float* da_out, float* dct_out, float* dht_out, int L, int B, int ndir, hipStream_t stream)
 {
     constexpr int H = NW * 32;
     constexpr bool RES = (NW <= 4);
@@ -358,7 +368,7 @@ int launch_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const in
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GMT_ERR_HIP;
     hipLaunchKernelGGL(k, dim3(n_tiles * ndir), dim3(NW * 64), lds, stream, gates, c_all, w_hh_pkT, lengths,
-                       dh_all, dh_final, dgates_extra, dc_extra, L, B, ndir, n_tiles);
+                       dh_all, dh_final, dgates_extra, dc_extra, da_out, dct_out, dht_out, L, B, ndir, n_tiles);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }
@@ -395,12 +405,13 @@ extern "C" int gmt_lstm_layer_fwd(const float* x, const float* pregates, const f
 
 extern "C" int gmt_lstm_layer_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths,
                                   const float* dh_all, const float* dh_final, const float* dgates_extra,
-                                  const float* dc_extra, int L, int B, int H, int ndir, hipStream_t stream)
+                                  const float* dc_extra, float* da_out, float* dct_out, float* dht_out,
+                                  int L, int B, int H, int ndir, hipStream_t stream)
 {
     GMT_CHECK_ARG(gates && c_all && w_hh_pkT && L >= 1 && B >= GMT_TM && (B % GMT_TM) == 0 && (ndir == 1 || ndir == 2));
     switch (H) {
 #define GMT_CASE(NW) case NW * 32: return launch_bwd<NW>(gates, c_all, w_hh_pkT, lengths, dh_all, dh_final, \
-                                                         dgates_extra, dc_extra, L, B, ndir, stream);
+                                                         dgates_extra, dc_extra, da_out, dct_out, dht_out, L, B, ndir, stream);
         GMT_CASE(1) GMT_CASE(2) GMT_CASE(4) GMT_CASE(8)
 #undef GMT_CASE
         default: return GMT_ERR_UNSUPPORTED;

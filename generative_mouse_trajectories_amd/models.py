@@ -142,7 +142,8 @@ class Generator(nn.Module):
         out = ops.GenRolloutFn.apply(g0, w_u, lp.weight_hh_l0, lp.weight_ih_l1, lp.weight_hh_l1, bias1,
                                      self.output_layer[0].weight, self.output_layer[0].bias,
                                      self.output_layer[2].weight, self.output_layer[2].bias,
-                                     self.initial_input, s_p, e_p, target_tm, tf_mask, T)
+                                     self.initial_input, s_p, e_p, target_tm, tf_mask, T,
+                                     torch.is_grad_enabled())
         return out[:, :B]
 
     def forward(self, start, end, z, target_sequences: Optional[torch.Tensor] = None,

@@ -113,14 +113,14 @@ class LSTMLayerFn(torch.autograd.Function):
             w_ih_pk = pack_forward(w_ih, H, I)
             L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(w_ih_pk), L_.ptr(w_hh_pk), L_.ptr(bias),
                     L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
-                    L, B, I, H, nd, L_.stream())
+                    L, B, I, H, nd, L_.stream(), label=f'lstm_fwd_fused_I{I // H}')
         else:
             x2 = x.view(L * B, I)
             for d in range(nd):
                 torch.addmm(bias[d], x2, w_ih[d].detach().t(), out=gates[d].view(L * B, 4 * H))
             L_.call('gmt_lstm_layer_fwd', None, L_.ptr(gates), None, L_.ptr(w_hh_pk), None,
                     L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
-                    L, B, I, H, nd, L_.stream())
+                    L, B, I, H, nd, L_.stream(), label='lstm_fwd_pregates')
         ctx.save_for_backward(x, lengths, gates, c_all, h_all, *weights)
         ctx.dims = (L, B, I, H, nd)
         ctx.set_materialize_grads(False)
@@ -139,7 +139,7 @@ class LSTMLayerFn(torch.autograd.Function):
         w_hh_pkT = pack_transposed(w_hh, H, 4 * H)
         # `gates` is overwritten in place with d(pre-activation): the graph can be back-propagated once
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
-                L_.ptr(dh_all), L_.ptr(dh_final), None, None, L, B, H, nd, L_.stream())
+                L_.ptr(dh_all), L_.ptr(dh_final), None, None, None, None, None, L, B, H, nd, L_.stream(), label='lstm_bwd')
         da = gates
         x2 = x.view(L * B, I)
         grads: List[Optional[torch.Tensor]] = []
@@ -171,6 +171,140 @@ class LSTMLayerFn(torch.autograd.Function):
 
 def lstm_layer(x, lengths_i32, weights, fuse_x: bool = True, need_h_all: bool = True):
     return LSTMLayerFn.apply(x, lengths_i32, fuse_x, need_h_all, *weights)
+
+
+def _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd):
+    """dW_ih, dW_hh, db per direction from d(pre-activation) [nd,L,B,4H] (one GEMM each)."""
+    grads = []
+    for d in range(nd):
+        da2 = da[d].view(L * B, 4 * H)
+        d_wih = torch.mm(da2.t(), x2)
+        hv = h_all.view(L * B, nd * H)[:, d * H:(d + 1) * H]
+        if L > 1:
+            d_whh = torch.mm(da2[B:].t(), hv[:-B]) if d == 0 else torch.mm(da2[:-B].t(), hv[B:])
+        else:
+            d_whh = torch.zeros_like(w_hh[d])
+        db = da2.sum(0)
+        grads += [d_wih, d_whh, db, db]
+    return grads
+
+
+class LSTMLayerBwdGPFn(torch.autograd.Function):
+    """The first backward sweep of a layer as a differentiable op (gradient penalty only):
+    (dh_all, dh_final, gates, c_all, w_ih.., w_hh..) -> dx.  Its backward is the second-order
+    kernel gmt_lstm_layer_bwd2."""
+
+    @staticmethod
+    def forward(ctx, dh_all, dh_final, gates, c_all, lengths, I, *w):
+        nd = len(w) // 2
+        w_ih, w_hh = list(w[:nd]), list(w[nd:])
+        _, L, B, H4 = gates.shape
+        H = H4 // 4
+        dev = gates.device
+        if dh_all is not None:
+            dh_all = dh_all.contiguous()
+        if dh_final is not None:
+            dh_final = dh_final.contiguous()
+        da = torch.empty_like(gates)
+        dct = torch.empty(nd, L, B, H, device=dev, dtype=torch.float32)
+        dht = torch.empty(nd, L, B, H, device=dev, dtype=torch.float32)
+        w_hh_pkT = pack_transposed(w_hh, H, 4 * H)
+        L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
+                L_.ptr(dh_all), L_.ptr(dh_final), None, None, L_.ptr(da), L_.ptr(dct), L_.ptr(dht),
+                L, B, H, nd, L_.stream(), label='lstm_bwd_gp')
+        dx = torch.mm(da[0].view(L * B, 4 * H), w_ih[0].detach())
+        for d in range(1, nd):
+            dx.addmm_(da[d].view(L * B, 4 * H), w_ih[d].detach())
+        ctx.save_for_backward(gates, c_all, lengths, da, dct, dht, *w)
+        ctx.dims = (L, B, I, H, nd)
+        ctx.has = (dh_all is not None, dh_final is not None)
+        return dx.view(L, B, I)
+
+    @staticmethod
+    def backward(ctx, xhat):
+        gates, c_all, lengths, da, dct, dht, *w = ctx.saved_tensors
+        L, B, I, H, nd = ctx.dims
+        w_ih, w_hh = list(w[:nd]), list(w[nd:])
+        dev = xhat.device
+        xhat = xhat.contiguous()
+        hhat_all = torch.empty(L, B, nd * H, device=dev, dtype=torch.float32)
+        hhat_final = torch.empty(B, nd * H, device=dev, dtype=torch.float32)
+        g_gates = torch.empty_like(gates)
+        g_c = torch.empty_like(c_all)
+        w_ih_pk = pack_forward(w_ih, H, I)
+        w_hh_pk = pack_forward(w_hh, H, H)
+        L_.call('gmt_lstm_layer_bwd2', L_.ptr(xhat), L_.ptr(w_ih_pk), L_.ptr(w_hh_pk), L_.ptr(lengths),
+                L_.ptr(gates), L_.ptr(c_all), L_.ptr(dct), L_.ptr(dht), L_.ptr(hhat_all), L_.ptr(hhat_final),
+                L_.ptr(g_gates), L_.ptr(g_c), L, B, I, H, nd, L_.stream(), label='lstm_bwd2')
+        xh2 = xhat.view(L * B, I)
+        g_wih, g_whh = [], []
+        for d in range(nd):
+            da2 = da[d].view(L * B, 4 * H)
+            g_wih.append(torch.mm(da2.t(), xh2))
+            hv = hhat_all.view(L * B, nd * H)[:, d * H:(d + 1) * H]
+            if L > 1:
+                g_whh.append(torch.mm(da2[B:].t(), hv[:-B]) if d == 0 else torch.mm(da2[:-B].t(), hv[B:]))
+            else:
+                g_whh.append(torch.zeros_like(w_hh[d]))
+        return (hhat_all if ctx.has[0] else None, hhat_final if ctx.has[1] else None, g_gates, g_c, None, None,
+                *g_wih, *g_whh)
+
+
+class LSTMLayerGPFn(torch.autograd.Function):
+    """Twice-differentiable variant of LSTMLayerFn for the gradient penalty: the saved
+    activations are outputs, so that the adjoints the second-order sweep produces for them
+    flow back into this layer's (ordinary) backward kernel as extra adjoints."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, *weights):
+        nd = len(weights) // 4
+        w_ih = [weights[4 * d] for d in range(nd)]
+        w_hh = [weights[4 * d + 1] for d in range(nd)]
+        H = w_hh[0].shape[1]
+        L, B, I = x.shape
+        assert B % TM == 0
+        x = x.contiguous()
+        dev = x.device
+        bias = torch.stack([weights[4 * d + 2].detach() + weights[4 * d + 3].detach() for d in range(nd)]).contiguous()
+        gates = torch.empty(nd, L, B, 4 * H, device=dev, dtype=torch.float32)
+        c_all = torch.empty(nd, L, B, H, device=dev, dtype=torch.float32)
+        h_all = torch.empty(L, B, nd * H, device=dev, dtype=torch.float32)
+        h_final = torch.empty(B, nd * H, device=dev, dtype=torch.float32)
+        L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(pack_forward(w_ih, H, I)), L_.ptr(pack_forward(w_hh, H, H)),
+                L_.ptr(bias), L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
+                L, B, I, H, nd, L_.stream(), label=f'lstm_fwd_gp_I{I // H}')
+        ctx.save_for_backward(x, lengths, gates, c_all, h_all, *weights)
+        ctx.dims = (L, B, I, H, nd)
+        ctx.set_materialize_grads(False)
+        return h_all, h_final, gates, c_all
+
+    @staticmethod
+    def backward(ctx, dh_all, dh_final, dgates, dc):
+        x, lengths, gates, c_all, h_all, *weights = ctx.saved_tensors
+        L, B, I, H, nd = ctx.dims
+        w_ih = [weights[4 * d] for d in range(nd)]
+        w_hh = [weights[4 * d + 1] for d in range(nd)]
+        if torch.is_grad_enabled():
+            # first backward under create_graph=True: only the input gradient is produced (this is
+            # what torch.autograd.grad(inputs=interpolated) of the penalty asks for), as a
+            # differentiable op
+            dx = LSTMLayerBwdGPFn.apply(dh_all, dh_final, gates, c_all, lengths, I, *w_ih, *w_hh)
+            return (dx, None) + (None,) * len(weights)
+        cont = lambda t: None if t is None else t.contiguous()
+        dh_all, dh_final, dgates, dc = cont(dh_all), cont(dh_final), cont(dgates), cont(dc)
+        da = torch.empty_like(gates)
+        w_hh_pkT = pack_transposed(w_hh, H, 4 * H)
+        L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
+                L_.ptr(dh_all), L_.ptr(dh_final), L_.ptr(dgates), L_.ptr(dc), L_.ptr(da), None, None,
+                L, B, H, nd, L_.stream(), label='lstm_bwd_gp2')
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(da[0].view(L * B, 4 * H), w_ih[0])
+            for d in range(1, nd):
+                dx.addmm_(da[d].view(L * B, 4 * H), w_ih[d])
+            dx = dx.view(L, B, I)
+        grads = _lstm_weight_grads(da, x.view(L * B, I), h_all, w_hh, L, B, H, nd)
+        return (dx, None, *grads)
 
 
 # ----------------------------------------------------------------------------------------
@@ -205,7 +339,8 @@ class GenRolloutFn(torch.autograd.Function):
     Output: out_seq [T,B,3].  B % 32 == 0."""
 
     @staticmethod
-    def forward(ctx, g0, w_u, w_hh0, w_ih1, w_hh1, bias1, w1, b1, w2, b2, init_in, starts, ends, target, tf_mask, T):
+    def forward(ctx, g0, w_u, w_hh0, w_ih1, w_hh1, bias1, w1, b1, w2, b2, init_in, starts, ends, target, tf_mask, T,
+                save_for_bwd=True):
         L_.require_cuda(g0)
         B, H4 = g0.shape
         H = H4 // 4
@@ -213,7 +348,7 @@ class GenRolloutFn(torch.autograd.Function):
         NW = H // 32
         dev = g0.device
         assert B % TM == 0
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = any(ctx.needs_input_grad) and save_for_bwd
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         a = L_.GenFwdArgs()
         keep = []
@@ -245,7 +380,8 @@ class GenRolloutFn(torch.autograd.Function):
             a.gates1 = saved['gates1'].data_ptr(); a.c1_all = saved['c1'].data_ptr(); a.h1_all = saved['h1'].data_ptr()
             a.u_all = saved['u'].data_ptr(); a.y_all = saved['y'].data_ptr(); a.oraw_all = saved['oraw'].data_ptr()
         a.T, a.B, a.H = T, B, H
-        L_.call('gmt_gen_rollout_fwd', ctypes_byref(a), L_.stream())
+        L_.call('gmt_gen_rollout_fwd', ctypes_byref(a), L_.stream(),
+                label='gen_fwd_train' if need_grad else 'gen_fwd_nograd')
         if need_grad:
             ctx.save_for_backward(w_u, w_hh0, w_ih1, w_hh1, w1, w2, tf_mask if tf_mask is not None else torch.empty(0),
                                   *saved.values())
@@ -296,7 +432,7 @@ class GenRolloutFn(torch.autograd.Function):
         d_b2 = dov.sum(0)
         d_init = d_in0.sum(0).reshape(ctx.init_shape)
         return (d_g0, d_w_u, d_w_hh0, d_w_ih1, d_w_hh1, d_bias1, d_w1, d_b1, d_w2, d_b2, d_init,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 def ctypes_byref(a):

@@ -124,7 +124,7 @@ def _make_writer(log_dir: str):
 # ------------------------------------------------------------------------------------------
 def compute_gradient_penalty(discriminator: Discriminator, real_trajectories, fake_trajectories, real_dts, fake_dts,
                              lengths, device, alpha: Optional[torch.Tensor] = None) -> torch.Tensor:
-    from .composite import discriminator_forward_torch
+    from .composite import discriminator_forward_gp
     batch_size = real_trajectories.shape[0]
     min_len = min(real_trajectories.shape[1], fake_trajectories.shape[1])
     real_trajectories, fake_trajectories = real_trajectories[:, :min_len], fake_trajectories[:, :min_len]
@@ -136,7 +136,7 @@ def compute_gradient_penalty(discriminator: Discriminator, real_trajectories, fa
     alpha_dt = alpha.squeeze(-1)
     interpolated = (alpha * real_trajectories + (1 - alpha) * fake_trajectories).detach().requires_grad_(True)
     interpolated_dts = alpha_dt * real_dts + (1 - alpha_dt) * fake_dts
-    d_interpolated = discriminator_forward_torch(discriminator, interpolated, interpolated_dts, lengths)
+    d_interpolated = discriminator_forward_gp(discriminator, interpolated, interpolated_dts, lengths)
     gradients = torch.autograd.grad(outputs=d_interpolated, inputs=interpolated,
                                     grad_outputs=torch.ones_like(d_interpolated),
                                     create_graph=True, retain_graph=True)[0]

@@ -109,10 +109,25 @@ int gmt_lstm_layer_fwd(const float* x, const float* pregates, const float* w_ih_
  * stride_k H, stride_n 1).  Out: `gates` is overwritten with d(pre-activation) (zero at
  * padded steps); the caller contracts it with x / h_prev / W_ih for dW and dx.
  * dgates_extra / dc_extra: optional additional adjoints of the saved activations (used by
- * the gradient-penalty double backward).  H in {32, 64, 128}. */
+ * the gradient-penalty double backward).  da_out: when non-NULL, d(pre-activation) goes
+ * there and `gates` is left intact; dct_out / dht_out [ndir][L][B][H]: optional, the total
+ * cell / hidden adjoint of every step (inputs of gmt_lstm_layer_bwd2).  H in {32,64,128,256}. */
 int gmt_lstm_layer_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths,
                        const float* dh_all, const float* dh_final, const float* dgates_extra,
-                       const float* dc_extra, int L, int B, int H, int ndir, hipStream_t stream);
+                       const float* dc_extra, float* da_out, float* dct_out, float* dht_out,
+                       int L, int B, int H, int ndir, hipStream_t stream);
+
+/* gmt_lstm_layer_bwd2: adjoint of gmt_lstm_layer_bwd itself - the LSTM part of
+ * torch.autograd.grad(..., create_graph=True) in compute_gradient_penalty, RG.py:829-835.
+ * In: xhat [L][B][I] = adjoint of dX, the forward-packed weights, the saved gates / c_all
+ * and the dct / dht buffers of the first backward sweep.  Out: hhat_all [L][B][ndir*H]
+ * (adjoint of dh_all; may be NULL), hhat_final [B][ndir*H] (adjoint of dh_final; may be
+ * NULL), g_gates [ndir][L][B][4H] and g_c [ndir][L][B][H] (adjoints of the saved
+ * activations, to be passed to gmt_lstm_layer_bwd as dgates_extra / dc_extra). */
+int gmt_lstm_layer_bwd2(const float* xhat, const float* w_ih_pk, const float* w_hh_pk, const int* lengths,
+                        const float* gates, const float* c_all, const float* dct_all, const float* dht_all,
+                        float* hhat_all, float* hhat_final, float* g_gates, float* g_c,
+                        int L, int B, int I, int H, int ndir, hipStream_t stream);
 
 /* ---- persistent generator rollout -----------------------------------------------------------
  * Replaces the autoregressive loop of Generator.forward, RG.py:508-604 (dynamic features
