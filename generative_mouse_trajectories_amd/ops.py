@@ -270,7 +270,9 @@ class LSTMLayerGPFn(torch.autograd.Function):
         c_all = torch.empty(nd, L, B, H, device=dev, dtype=torch.float32)
         h_all = torch.empty(L, B, nd * H, device=dev, dtype=torch.float32)
         h_final = torch.empty(B, nd * H, device=dev, dtype=torch.float32)
-        L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(pack_forward(w_ih, H, I)), L_.ptr(pack_forward(w_hh, H, H)),
+        w_ih_pk = pack_forward(w_ih, H, I)      # keep both alive until the launch is enqueued
+        w_hh_pk = pack_forward(w_hh, H, H)
+        L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(w_ih_pk), L_.ptr(w_hh_pk),
                 L_.ptr(bias), L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
                 L, B, I, H, nd, L_.stream(), label=f'lstm_fwd_gp_I{I // H}')
         ctx.save_for_backward(x, lengths, gates, c_all, h_all, *weights)
