@@ -104,6 +104,15 @@ class FusedAdam(torch.optim.Optimizer):
                 st[key] = view
 
 
+def allreduce_flat_grad(flat: FlatParams, world_size: int, group=None) -> None:
+    """Data-parallel gradient exchange: ONE sum all-reduce (RCCL over xGMI on the GPUs, gloo in
+    the CPU tests) of the model's flat gradient buffer; the 1/world_size factor is applied by
+    the fused Adam kernel (grad_scale)."""
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=group)
+
+
 class _NullWriter:
     def add_scalar(self, *a, **k): pass
     def add_figure(self, *a, **k): pass
@@ -186,9 +195,7 @@ class Trainer:
         return c.teacher_forcing_start - progress * (c.teacher_forcing_start - c.teacher_forcing_end)
 
     def _allreduce(self, flat: FlatParams):
-        if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=self.process_group)
+        allreduce_flat_grad(flat, self.world_size, self.process_group)
 
     def _to_dev(self, batch: Dict):
         d = self.device

@@ -393,7 +393,7 @@ def discriminator_step(P_g: Params, P_d: Params, bufs_d: Params, opt_d: Dict, ba
     grads = dict(zip(names, gl))
     if apply_update:
         adam_update(P_d, grads, opt_d, cfg.learning_rate, cfg.betas)
-    metrics = {'d_loss': float(d_loss), 'd_gp': float(gp),
+    metrics = {'d_loss': float(d_loss.detach()), 'd_gp': float(gp.detach()),
                'd_real_score': float(real_score.mean()), 'd_fake_score': float(fake_score.mean())}
     aux = {'fake_sequences': fake_seq, 'real_score': real_score.detach(), 'fake_score': fake_score.detach()}
     return metrics, grads, aux
