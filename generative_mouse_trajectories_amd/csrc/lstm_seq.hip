@@ -249,18 +249,43 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
         dc[r] = 0.f;
     }
 
+    // Software pipeline: the saved activations of the NEXT step are fetched into registers
+    // right after the barrier that opens the MFMA phase, so their HBM latency and transfer
+    // run under the contraction (the element-wise phase then starts with its operands in
+    // registers).  c_t is carried from the previous step's c_prev fetch.
+    float pg[4][16], pcp[16], pdy[16], cn_c[16];
+    auto prefetch = [&](int t) {
+        const int tp = dir ? t + 1 : t - 1;
+        const bool tp_ok = (tp >= 0) && (tp < L);
+        const size_t rs = ((size_t)dir * L + t) * B + lane_row;
+        const float* gp = gates + rs * (4 * H) + col;
+        const float* cp_p = c_all + (((size_t)dir * L + (tp_ok ? tp : t)) * B + lane_row) * H + col;
+        const float* dy_p = dh_all ? dh_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col : nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2);
+            const float* q = gp + (size_t)mr * (4 * H);
+            pg[0][r] = q[0]; pg[1][r] = q[H]; pg[2][r] = q[2 * H]; pg[3][r] = q[3 * H];
+            pcp[r] = tp_ok ? cp_p[(size_t)mr * H] : 0.f;
+            pdy[r] = dy_p ? dy_p[(size_t)mr * (ndir * H)] : 0.f;
+        }
+    };
+    if (tmax > 0) {
+        const int t0 = dir ? 0 : tmax - 1;
+        prefetch(t0);
+        const float* cn_p = c_all + (((size_t)dir * L + t0) * B + lane_row) * H + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cn_c[r] = cn_p[(size_t)((r & 3) + 8 * (r >> 2)) * H];
+    }
+
     // forward visited t in order (dir 0: 0..tmax-1, dir 1: tmax-1..0); walk it backwards
     for (int step = tmax - 1; step >= 0; --step) {
         const int t = dir ? (tmax - 1 - step) : step;
         const int tp = dir ? t + 1 : t - 1;            // the step the forward pass visited before t
         const size_t rs = ((size_t)dir * L + t) * B + lane_row;
-        float* gp = gates + rs * (4 * H) + col;
         float* wp = (da_out ? da_out : gates) + rs * (4 * H) + col;
         float* dct_p = dct_out ? dct_out + rs * H + col : nullptr;
         float* dht_p = dht_out ? dht_out + rs * H + col : nullptr;
-        const float* cn_p = c_all + rs * H + col;
-        const float* cp_p = c_all + (((size_t)dir * L + (tp < 0 ? 0 : tp)) * B + lane_row) * H + col;
-        const float* dy_p = dh_all ? dh_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col : nullptr;
         const float* ge_p = dgates_extra ? dgates_extra + rs * (4 * H) + col : nullptr;
         const float* ce_p = dc_extra ? dc_extra + rs * H + col : nullptr;
         f32x16 acc[1];
@@ -271,14 +296,12 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
             const int ln = s_len[m];
             const bool act = t < ln;
             float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f, dct_s = 0.f, dht_s = 0.f;
-            float* q = gp + (size_t)mr * (4 * H);
             if (act) {
-                const float ig = q[0], fg = q[H], gg = q[2 * H], og = q[3 * H];
-                const float cn = cn_p[(size_t)mr * H];
+                const float ig = pg[0][r], fg = pg[1][r], gg = pg[2][r], og = pg[3][r];
+                const float cn = cn_c[r];
                 const bool has_prev = dir ? (tp < ln) : (tp >= 0);
-                const float cp = has_prev ? cp_p[(size_t)mr * H] : 0.f;
-                float dht = dh[r];
-                if (dy_p) dht += dy_p[(size_t)mr * (ndir * H)];
+                const float cp = has_prev ? pcp[r] : 0.f;
+                const float dht = dh[r] + pdy[r];
                 const float tc = gmt_tanh(cn);
                 float dog = dht * tc;
                 float dct = dc[r] + dht * og * (1.f - tc * tc);
@@ -298,6 +321,7 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
             } else {
                 acc[0][r] = dh[r];                     // frozen row: state passes through
             }
+            cn_c[r] = pcp[r];                          // c of the step processed next
             // d(pre-activation) replaces the gates (zero at padded steps: the weight-gradient GEMM reads it)
             float* w = wp + (size_t)mr * (4 * H);
             w[0] = dai; w[H] = daf; w[2 * H] = dag; w[3 * H] = dao;
@@ -309,6 +333,7 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
             daT[(3 * H + col) * GMT_LDA + m] = dao;
         }
         __syncthreads();
+        if (step > 0) prefetch(dir ? t + 1 : t - 1);
         if constexpr (RES) gmt_mma_resident<1, KS>(acc, daT, wr, lane);
         else gmt_mma_stream<1>(acc, daT, wT, 4 * H, lane);
 #pragma unroll
