@@ -48,6 +48,8 @@ _SIGS = {
     'gmt_lstm_layer_fwd': [c_p] * 10 + [c_i] * 5 + [c_p],
     'gmt_lstm_layer_bwd': [c_p] * 11 + [c_i] * 4 + [c_p],
     'gmt_lstm_layer_bwd2': [c_p] * 12 + [c_i] * 5 + [c_p],
+    'gmt_wgrad_workspace_floats': [c_i, c_i, c_ll, c_p, c_p],
+    'gmt_wgrad': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_ll, c_p],
     'gmt_gen_rollout_fwd': [c_p, c_p],
     'gmt_gen_rollout_bwd': [c_p, c_p],
 }
@@ -114,7 +116,7 @@ def profile_stop():
 
 def call(name, *args, label=None):
     fn = getattr(lib(), name)
-    if PROFILE is not None:
+    if PROFILE is not None and label != 'skip':
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()

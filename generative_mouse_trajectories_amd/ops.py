@@ -86,6 +86,30 @@ def pack_transposed(ws: List[torch.Tensor], n_out: int, K: int, col0: int = 0, n
 
 
 # ----------------------------------------------------------------------------------------
+# weight-gradient contraction over time (split-K MFMA kernel, csrc/wgrad.hip)
+# ----------------------------------------------------------------------------------------
+def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False):
+    """dW = dA^T X over the rows (dA [R,N] contiguous, X [R,I] a row-strided view); optionally
+    db = dA.sum(0).  Shapes outside the kernel's tiling (N % 256, I % 128, R % 32) go to rocBLAS."""
+    R, N = dA.shape
+    I = X.shape[1]
+    ok = (N % 256 == 0 and I % 128 == 0 and R % 32 == 0 and R >= 32 and dA.is_contiguous()
+          and X.stride(1) == 1 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and dA.data_ptr() % 16 == 0)
+    if not ok:
+        dW = torch.mm(dA.t(), X)
+        return dW, (dA.sum(0) if want_db else None)
+    import ctypes
+    ks, need = ctypes.c_int(0), ctypes.c_longlong(0)
+    L_.call('gmt_wgrad_workspace_floats', N, I, R, ctypes.addressof(ks), ctypes.addressof(need), label='skip')
+    ws = torch.empty(need.value, device=dA.device, dtype=torch.float32)
+    dW = torch.empty(N, I, device=dA.device, dtype=torch.float32)
+    db = torch.empty(N, device=dA.device, dtype=torch.float32) if want_db else None
+    L_.call('gmt_wgrad', dA.data_ptr(), N, X.data_ptr(), X.stride(0), R, N, I, dW.data_ptr(),
+            None if db is None else db.data_ptr(), 0, ws.data_ptr(), need.value, L_.stream(), label=f'wgrad_I{I}')
+    return dW, db
+
+
+# ----------------------------------------------------------------------------------------
 # packed bidirectional LSTM layer (RecurrentGAN.py:720-727, 764-778)
 # ----------------------------------------------------------------------------------------
 class LSTMLayerFn(torch.autograd.Function):
@@ -150,22 +174,10 @@ class LSTMLayerFn(torch.autograd.Function):
                 dx.addmm_(da[d].view(L * B, 4 * H), w_ih[d])
             dx = dx.view(L, B, I)
         need_w = any(ctx.needs_input_grad[4:])
-        for d in range(nd):
-            if not need_w:
-                grads += [None, None, None, None]
-                continue
-            da2 = da[d].view(L * B, 4 * H)
-            d_wih = torch.mm(da2.t(), x2)
-            hv = h_all.view(L * B, nd * H)[:, d * H:(d + 1) * H]
-            if L > 1:
-                if d == 0:      # forward direction: h_prev(t) = h[t-1]
-                    d_whh = torch.mm(da2[B:].t(), hv[:-B])
-                else:           # reverse direction: h_prev(t) = h[t+1] (zero beyond the row's length)
-                    d_whh = torch.mm(da2[:-B].t(), hv[B:])
-            else:
-                d_whh = torch.zeros_like(w_hh[d])
-            db = da2.sum(0)
-            grads += [d_wih, d_whh, db, db]
+        if need_w:
+            grads = _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd)
+        else:
+            grads = [None] * (4 * nd)
         return (dx, None, None, None, *grads)
 
 
@@ -174,17 +186,17 @@ def lstm_layer(x, lengths_i32, weights, fuse_x: bool = True, need_h_all: bool = 
 
 
 def _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd):
-    """dW_ih, dW_hh, db per direction from d(pre-activation) [nd,L,B,4H] (one GEMM each)."""
+    """dW_ih, dW_hh, db per direction from d(pre-activation) [nd,L,B,4H] (one contraction each)."""
     grads = []
     for d in range(nd):
         da2 = da[d].view(L * B, 4 * H)
-        d_wih = torch.mm(da2.t(), x2)
+        d_wih, db = wgrad(da2, x2, want_db=True)
         hv = h_all.view(L * B, nd * H)[:, d * H:(d + 1) * H]
         if L > 1:
-            d_whh = torch.mm(da2[B:].t(), hv[:-B]) if d == 0 else torch.mm(da2[:-B].t(), hv[B:])
+            # forward direction: h_prev(t) = h[t-1]; reverse: h_prev(t) = h[t+1] (zero beyond the row's length)
+            d_whh, _ = wgrad(da2[B:], hv[:-B]) if d == 0 else wgrad(da2[:-B], hv[B:])
         else:
             d_whh = torch.zeros_like(w_hh[d])
-        db = da2.sum(0)
         grads += [d_wih, d_whh, db, db]
     return grads
 
@@ -240,10 +252,10 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         g_wih, g_whh = [], []
         for d in range(nd):
             da2 = da[d].view(L * B, 4 * H)
-            g_wih.append(torch.mm(da2.t(), xh2))
+            g_wih.append(wgrad(da2, xh2)[0])
             hv = hhat_all.view(L * B, nd * H)[:, d * H:(d + 1) * H]
             if L > 1:
-                g_whh.append(torch.mm(da2[B:].t(), hv[:-B]) if d == 0 else torch.mm(da2[:-B].t(), hv[B:]))
+                g_whh.append(wgrad(da2[B:], hv[:-B])[0] if d == 0 else wgrad(da2[:-B], hv[B:])[0])
             else:
                 g_whh.append(torch.zeros_like(w_hh[d]))
         return (hhat_all if ctx.has[0] else None, hhat_final if ctx.has[1] else None, g_gates, g_c, None, None,
@@ -422,10 +434,9 @@ class GenRolloutFn(torch.autograd.Function):
         h0v, h1v = h0.view(T * B, H), h1.view(T * B, H)
         d_g0 = gates0.sum(0)                                            # time-invariant input: sum over t
         d_w_u = torch.mm(da0.t(), u.view(T * B, 8))[:, :7]
-        d_w_hh0 = torch.mm(da0[B:].t(), h0v[:-B]) if T > 1 else torch.zeros_like(w_hh0)
-        d_w_ih1 = torch.mm(da1.t(), h0v)
-        d_w_hh1 = torch.mm(da1[B:].t(), h1v[:-B]) if T > 1 else torch.zeros_like(w_hh1)
-        d_bias1 = da1.sum(0)
+        d_w_hh0 = wgrad(da0[B:], h0v[:-B])[0] if T > 1 else torch.zeros_like(w_hh0)
+        d_w_ih1, d_bias1 = wgrad(da1, h0v, want_db=True)
+        d_w_hh1 = wgrad(da1[B:], h1v[:-B])[0] if T > 1 else torch.zeros_like(w_hh1)
         dyp = d_ypre.view(T * B, HH)
         d_w1 = torch.mm(dyp.t(), h1v)
         d_b1 = dyp.sum(0)

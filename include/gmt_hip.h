@@ -129,6 +129,17 @@ int gmt_lstm_layer_bwd2(const float* xhat, const float* w_ih_pk, const float* w_
                         float* hhat_all, float* hhat_final, float* g_gates, float* g_c,
                         int L, int B, int I, int H, int ndir, hipStream_t stream);
 
+/* ---- weight-gradient contraction over time -------------------------------------------------
+ * dW[n][i] (+)= sum_r dA[r][n] * X[r][i],  db[n] (+)= sum_r dA[r][n]  over R = L*B row-steps: the
+ * dW_ih / dW_hh / db GEMMs autograd runs for RG.py:1021, 1109.  Split-K fp32-MFMA kernel with a
+ * deterministic slab reduction.  N % 256 == 0, I % 128 == 0, R % 32 == 0; lda / ldx = row
+ * pitches in floats (multiples of 4); db may be NULL; accumulate != 0 adds to dW / db.
+ * gmt_wgrad_workspace_floats tells the caller how large `workspace` must be. */
+int gmt_wgrad_workspace_floats(int N, int I, long long R, int* ksplit_out, long long* floats_out);
+int gmt_wgrad(const float* dA, long long lda, const float* X, long long ldx, long long R, int N, int I,
+              float* dW, float* db, int accumulate, float* workspace, long long workspace_floats,
+              hipStream_t stream);
+
 /* ---- persistent generator rollout -----------------------------------------------------------
  * Replaces the autoregressive loop of Generator.forward, RG.py:508-604 (dynamic features
  * RG.py:486-506, nn.LSTM step RG.py:571, output_layer RG.py:460-464/574, softplus RG.py:577-580,

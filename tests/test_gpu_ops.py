@@ -154,3 +154,19 @@ def test_telemetry_kernel_bit_exact():
             tol = 1e-9 if k == 'idle_time' else 1e-12 * max(np.abs(ref).max(), 1.0)
             assert np.abs(der[j, :b - a, r] - ref).max() <= tol, (k, r)
     print('telemetry worst rel err', worst)
+
+
+@pytest.mark.parametrize('R,N,I,ldx,shift', [(32 * 40, 512, 128, 256, 0), (32 * 129, 512, 256, 256, 32),
+                                            (32 * 700, 512, 128, 128, 0), (64, 256, 128, 128, 0)])
+def test_wgrad_kernel(ops, R, N, I, ldx, shift):
+    torch.manual_seed(R + I)
+    dA = torch.randn(R + shift, N, device=DEV)
+    Xf = torch.randn(R + shift, ldx, device=DEV)
+    X = Xf[:, ldx - I:] if ldx > I else Xf
+    a, x = dA[shift:], X[:R]
+    dW, db = ops.wgrad(a, x, want_db=True)
+    ref = a.double().t() @ x.double()
+    H.assert_close(dW, ref, 2e-6, 'dW')
+    H.assert_close(db, a.double().sum(0), 2e-6, 'db')
+    dW2, _ = ops.wgrad(a, x)
+    assert torch.equal(dW, dW2), 'the slab reduction must be deterministic'
