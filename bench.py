@@ -111,7 +111,6 @@ def main():
     cfg = gmt.Config()
     cfg.latent_dim, cfg.generator_hidden_dim, cfg.discriminator_hidden_dim = LATENT, HID, HID
     cfg.batch_size = args.batch
-    cfg.lstm_dropout = 0.0      # TODO(round 1): dropout is not yet fused into the recurrent kernels
     torch.manual_seed(0)        # identical replicas on every rank
     G, D = gmt.Generator(cfg), gmt.Discriminator(cfg)
     tr = gmt.Trainer(G, D, cfg, dev, log_dir='/tmp/gmt_runs', world_size=world, process_group=pg)

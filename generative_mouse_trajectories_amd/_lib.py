@@ -27,14 +27,15 @@ c_d = ctypes.c_double
 class GenFwdArgs(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ('g0', 'w_u_pk', 'w_hh0_pk', 'w_ih1_pk', 'w_hh1_pk', 'bias1', 'w1_pk', 'b1', 'w2',
                                    'b2', 'starts', 'ends', 'init_in', 'target', 'tf_mask', 'out_seq', 'gates0',
-                                   'c0_all', 'h0_all', 'gates1', 'c1_all', 'h1_all', 'u_all', 'y_all', 'oraw_all')] \
-        + [('T', c_i), ('B', c_i), ('H', c_i)]
+                                   'c0_all', 'h0_all', 'gates1', 'c1_all', 'h1_all', 'u_all', 'y_all', 'oraw_all', 'h0d_all')] \
+        + [('T', c_i), ('B', c_i), ('H', c_i), ('dropout_p', c_f), ('seed', ctypes.c_uint)]
 
 
 class GenBwdArgs(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ('gates0', 'c0_all', 'gates1', 'c1_all', 'y_all', 'oraw_all', 'u_all', 'd_out',
                                    'w1T_pk', 'w_l1T_pk', 'w_hh0T_pk', 'w_uP', 'w2', 'tf_mask', 'd_ypre', 'd_o',
-                                   'd_in0')] + [('T', c_i), ('B', c_i), ('H', c_i)]
+                                   'd_in0')] + [('T', c_i), ('B', c_i), ('H', c_i), ('dropout_p', c_f),
+                                                ('seed', ctypes.c_uint)]
 
 
 _SIGS = {

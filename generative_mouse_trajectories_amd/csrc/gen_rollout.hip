@@ -27,9 +27,14 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
     constexpr int H = NW * 32, KS = H / 2, HH = H / 2, NH = (HH + 31) / 32, NT = NW * 64;
     extern __shared__ float smem[];
     float* h0T = smem;                                 // [2][H][LDA]
-    float* h1T = h0T + 2 * H * GMT_LDA;                // [2][H][LDA]
-    float* yT = h1T + 2 * H * GMT_LDA;                 // [NH*32][LDA]
+    // H = 256 does not fit a double-buffered h1 next to the dropout buffer in 160 KB: it keeps ONE h1
+    // buffer and pays one more barrier per step (between layer 1's reads and its writes)
+    constexpr bool H1S = (NW > 4);
+    constexpr int H1B = H1S ? 1 : 2;
+    float* h1T = h0T + 2 * H * GMT_LDA;                // [H1B][H][LDA]
+    float* yT = h1T + H1B * H * GMT_LDA;               // [NH*32][LDA]
     float* uT = yT + NH * 32 * GMT_LDA;                // [8][LDA]
+    float* h0dT = uT + 8 * GMT_LDA;                    // [H][LDA] layer-0 output after dropout (dropout_p > 0)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -47,7 +52,10 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
     float wr0[4][RES0 ? KS : 1];
     if constexpr (RES0) gmt_load_resident<4, KS>(wr0, whh0, lane);
 
-    for (int i = tid; i < 4 * H * GMT_LDA + NH * 32 * GMT_LDA + 8 * GMT_LDA; i += NT) smem[i] = 0.f;
+    for (int i = tid; i < (2 + H1B) * H * GMT_LDA + NH * 32 * GMT_LDA + 8 * GMT_LDA; i += NT) smem[i] = 0.f;
+    const bool drop = a.dropout_p > 0.f;
+    const uint32_t thresh24 = (uint32_t)(a.dropout_p * 16777216.0f);
+    const float keep_scale = 1.0f / (1.0f - a.dropout_p);
 
     float bz1[4];
 #pragma unroll
@@ -103,6 +111,8 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
             float* sg = a.gates0 ? a.gates0 + rs * (4 * H) + col : nullptr;
             float* sc = a.c0_all ? a.c0_all + rs * H + col : nullptr;
             float* sh = a.h0_all ? a.h0_all + rs * H + col : nullptr;
+            float* shd = (a.h0d_all && drop) ? a.h0d_all + rs * H + col : nullptr;
+            float* hd = h0dT + col * GMT_LDA + 4 * hi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mr = (r & 3) + 8 * (r >> 2);
@@ -112,6 +122,12 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
                 const float hv = og * gmt_tanh(cn);
                 c0[r] = cn;
                 hn[mr] = hv;
+                if (drop) {
+                    const uint32_t idx = (uint32_t)((rs + mr) * H + col);
+                    const float hdv = gmt_keep(idx, a.seed, thresh24) ? hv * keep_scale : 0.f;
+                    hd[mr] = hdv;
+                    if (shd) shd[(size_t)mr * H] = hdv;
+                }
                 if (sg) { float* q = sg + (size_t)mr * (4 * H); q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og; }
                 if (sc) sc[(size_t)mr * H] = cn;
                 if (sh) sh[(size_t)mr * H] = hv;
@@ -125,9 +141,10 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][r] = bz1[g];
-            gmt_mma_stream<4>(acc, h0T + (size_t)(cur ^ 1) * H * GMT_LDA, wih1, H, lane);
-            gmt_mma_stream<4>(acc, h1T + (size_t)cur * H * GMT_LDA, whh1, H, lane);
-            float* hn = h1T + (size_t)(cur ^ 1) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
+            gmt_mma_stream<4>(acc, drop ? h0dT : h0T + (size_t)(cur ^ 1) * H * GMT_LDA, wih1, H, lane);
+            gmt_mma_stream<4>(acc, h1T + (size_t)(H1S ? 0 : cur) * H * GMT_LDA, whh1, H, lane);
+            if constexpr (H1S) __syncthreads();
+            float* hn = h1T + (size_t)(H1S ? 0 : (cur ^ 1)) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
             float* sg = a.gates1 ? a.gates1 + rs * (4 * H) + col : nullptr;
             float* sc = a.c1_all ? a.c1_all + rs * H + col : nullptr;
             float* sh = a.h1_all ? a.h1_all + rs * H + col : nullptr;
@@ -151,7 +168,7 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
             f32x16 acc[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][r] = b1v;
-            gmt_mma_stream<1>(acc, h1T + (size_t)(cur ^ 1) * H * GMT_LDA, w1, H, lane);
+            gmt_mma_stream<1>(acc, h1T + (size_t)(H1S ? 0 : (cur ^ 1)) * H * GMT_LDA, w1, H, lane);
             float* yp = yT + col * GMT_LDA + 4 * hi;
             float* sy = (a.y_all && col < HH) ? a.y_all + rs * HH + col : nullptr;
 #pragma unroll
@@ -236,6 +253,9 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dh0[r] = 0.f; dc0[r] = 0.f; dh1[r] = 0.f; dc1[r] = 0.f; }
     float din0 = 0.f, din1 = 0.f, din2 = 0.f, dpx = 0.f, dpy = 0.f;    // carried (threads 0..31)
+    const bool drop = a.dropout_p > 0.f;
+    const uint32_t thresh24 = (uint32_t)(a.dropout_p * 16777216.0f);
+    const float keep_scale = 1.0f / (1.0f - a.dropout_p);
     const size_t lane_row = (size_t)row0 + 4 * hi;
 
     for (int t = T - 1; t >= 0; --t) {
@@ -291,10 +311,18 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
         // ---- B4: dh1_prev = da1 W_hh1 ; dh0_total = dh0 + da1 W_ih1
         f32x16 acc2[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc2[0][r] = 0.f; acc2[1][r] = dh0[r]; }
+        for (int r = 0; r < 16; ++r) { acc2[0][r] = 0.f; acc2[1][r] = 0.f; }
         gmt_mma_stream<2>(acc2, daT, wl1T, 4 * H, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dh1[r] = acc2[0][r];
+        for (int r = 0; r < 16; ++r) {
+            dh1[r] = acc2[0][r];
+            float g = acc2[1][r];                      // gradient of layer 1's (dropped) input
+            if (drop) {
+                const uint32_t idx = (uint32_t)((rs + (r & 3) + 8 * (r >> 2)) * H + col);
+                g = gmt_keep(idx, a.seed, thresh24) ? g * keep_scale : 0.f;
+            }
+            acc2[1][r] = dh0[r] + g;
+        }
         __syncthreads();
         // ---- B5: layer-0 cell backward -> da0
         {
@@ -369,7 +397,7 @@ int launch_gen_fwd(const gmt_gen_fwd_args& a, hipStream_t stream)
 {
     constexpr int H = NW * 32, HH = H / 2, NH = (HH + 31) / 32;
     constexpr bool RES0 = (NW <= 4);
-    const size_t lds = (size_t)(4 * H + NH * 32 + 8) * GMT_LDA * sizeof(float);
+    const size_t lds = (size_t)((NW > 4 ? 3 : 4) * H + NH * 32 + 8 + H) * GMT_LDA * sizeof(float);
     if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;
     auto k = gen_fwd_kernel<NW, RES0>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

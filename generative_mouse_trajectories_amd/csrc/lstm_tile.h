@@ -35,6 +35,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <class T> __device__ __forceinline__ T* gmt_opaque_v(T* p) { asm volatile("" : "+v"(p)); return p; }
 template <class T> __device__ __forceinline__ T* gmt_opaque_s(T* p) { asm volatile("" : "+s"(p)); return p; }
 
+// Counter-based dropout mask (inter-layer LSTM dropout, RecurrentGAN.py:456): the keep decision of
+// element `idx` is a pure function of (seed, idx), so forward and backward regenerate the same
+// mask and nothing is stored.  PCG output hash on a Weyl-offset counter.
+__device__ __host__ __forceinline__ uint32_t gmt_hash32(uint32_t x) {
+    x = x * 747796405u + 2891336453u;
+    const uint32_t w = ((x >> ((x >> 28u) + 4u)) ^ x) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+__device__ __host__ __forceinline__ bool gmt_keep(uint32_t idx, uint32_t seed, uint32_t thresh24) {
+    return (gmt_hash32(idx + seed * 0x9E3779B1u) >> 8) >= thresh24;      // P(drop) = thresh24 / 2^24
+}
+
 // row of accumulator register r for this lane
 __device__ __forceinline__ int gmt_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

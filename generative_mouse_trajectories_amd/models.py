@@ -123,7 +123,8 @@ class Generator(nn.Module):
         angle = torch.atan2(diff[:, 1:2], diff[:, 0:1])
         return self.condition_encoder(torch.cat([start, end, distance, angle, z], dim=-1))
 
-    def _rollout(self, start, end, z, target_tm: Optional[torch.Tensor], tf_mask: Optional[torch.Tensor], T: int):
+    def _rollout(self, start, end, z, target_tm: Optional[torch.Tensor], tf_mask: Optional[torch.Tensor], T: int,
+                 dropout_seed: Optional[int] = None):
         """start/end (B,2), z (B,latent), target_tm (T,B,3) -> out (T,B,3); pads B to 32."""
         L_.require_cuda(start, end, z)
         H = self.config.generator_hidden_dim
@@ -139,22 +140,24 @@ class Generator(nn.Module):
         s_p, e_p = _pad_batch(start, Bp, 0), _pad_batch(end, Bp, 0)
         if target_tm is not None:
             target_tm = _pad_batch(target_tm, Bp, 1).contiguous()
+        # nn.LSTM(dropout=0.1) of RG.py:451-457: inter-layer dropout in training mode, fused into the kernel
+        p_drop = float(self.config.lstm_dropout) if self.training else 0.0
+        if dropout_seed is None:
+            dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
         out = ops.GenRolloutFn.apply(g0, w_u, lp.weight_hh_l0, lp.weight_ih_l1, lp.weight_hh_l1, bias1,
                                      self.output_layer[0].weight, self.output_layer[0].bias,
                                      self.output_layer[2].weight, self.output_layer[2].bias,
                                      self.initial_input, s_p, e_p, target_tm, tf_mask, T,
-                                     torch.is_grad_enabled())
+                                     torch.is_grad_enabled(), p_drop, dropout_seed)
         return out[:, :B]
 
     def forward(self, start, end, z, target_sequences: Optional[torch.Tensor] = None,
                 target_lengths: Optional[torch.Tensor] = None, teacher_forcing_ratio: float = 0.0,
-                tf_mask: Optional[Sequence[bool]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                tf_mask: Optional[Sequence[bool]] = None,
+                dropout_seed: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """RecurrentGAN.py:508-604.  `tf_mask` (optional, length T) replaces the per-step coin
         `torch.rand(1) < teacher_forcing_ratio` (RG.py:588) with explicit outcomes."""
         B = start.shape[0]
-        if self.training and self.config.lstm_dropout > 0:
-            raise NotImplementedError('inter-layer LSTM dropout is not fused into the rollout kernel yet; '
-                                      'set config.lstm_dropout = 0')
         if target_sequences is not None:
             T = target_sequences.shape[1]
             if tf_mask is None:
@@ -163,7 +166,7 @@ class Generator(nn.Module):
             tm = None
             if any(tf_mask):
                 tm = torch.tensor([1 if b else 0 for b in tf_mask], dtype=torch.uint8).to(start.device)
-            out = self._rollout(start, end, z, target_sequences.transpose(0, 1), tm, T)
+            out = self._rollout(start, end, z, target_sequences.transpose(0, 1), tm, T, dropout_seed)
         else:
             T = self.config.max_generation_steps
             out = self._rollout(start, end, z, None, None, T)

@@ -354,7 +354,7 @@ class GenRolloutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, g0, w_u, w_hh0, w_ih1, w_hh1, bias1, w1, b1, w2, b2, init_in, starts, ends, target, tf_mask, T,
-                save_for_bwd=True):
+                save_for_bwd=True, dropout_p=0.0, seed=0):
         L_.require_cuda(g0)
         B, H4 = g0.shape
         H = H4 // 4
@@ -393,7 +393,12 @@ class GenRolloutFn(torch.autograd.Function):
             a.gates0 = saved['gates0'].data_ptr(); a.c0_all = saved['c0'].data_ptr(); a.h0_all = saved['h0'].data_ptr()
             a.gates1 = saved['gates1'].data_ptr(); a.c1_all = saved['c1'].data_ptr(); a.h1_all = saved['h1'].data_ptr()
             a.u_all = saved['u'].data_ptr(); a.y_all = saved['y'].data_ptr(); a.oraw_all = saved['oraw'].data_ptr()
+        if need_grad and dropout_p > 0:
+            saved['h0d'] = f(T, B, H)
+            a.h0d_all = saved['h0d'].data_ptr()
         a.T, a.B, a.H = T, B, H
+        a.dropout_p, a.seed = float(dropout_p), int(seed) & 0xFFFFFFFF
+        ctx.drop = (float(dropout_p), int(seed) & 0xFFFFFFFF)
         L_.call('gmt_gen_rollout_fwd', ctypes_byref(a), L_.stream(),
                 label='gen_fwd_train' if need_grad else 'gen_fwd_nograd')
         if need_grad:
@@ -406,7 +411,8 @@ class GenRolloutFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
-        (w_u, w_hh0, w_ih1, w_hh1, w1, w2, tf_mask, gates0, c0, h0, gates1, c1, h1, u, y, oraw) = ctx.saved_tensors
+        (w_u, w_hh0, w_ih1, w_hh1, w1, w2, tf_mask, gates0, c0, h0, gates1, c1, h1, u, y, oraw, *rest) = ctx.saved_tensors
+        h0d = rest[0] if rest else h0                  # layer 1's input (after dropout when it is on)
         T, B, H = ctx.dims
         HH, NW = H // 2, H // 32
         dev = d_out.device
@@ -428,6 +434,7 @@ class GenRolloutFn(torch.autograd.Function):
         a.tf_mask = tf_mask.data_ptr() if ctx.has_tf else None
         a.d_ypre = d_ypre.data_ptr(); a.d_o = d_o.data_ptr(); a.d_in0 = d_in0.data_ptr()
         a.T, a.B, a.H = T, B, H
+        a.dropout_p, a.seed = ctx.drop
         L_.call('gmt_gen_rollout_bwd', ctypes_byref(a), L_.stream())
         da0 = gates0.view(T * B, 4 * H)
         da1 = gates1.view(T * B, 4 * H)
@@ -435,7 +442,7 @@ class GenRolloutFn(torch.autograd.Function):
         d_g0 = gates0.sum(0)                                            # time-invariant input: sum over t
         d_w_u = torch.mm(da0.t(), u.view(T * B, 8))[:, :7]
         d_w_hh0 = wgrad(da0[B:], h0v[:-B])[0] if T > 1 else torch.zeros_like(w_hh0)
-        d_w_ih1, d_bias1 = wgrad(da1, h0v, want_db=True)
+        d_w_ih1, d_bias1 = wgrad(da1, h0d.view(T * B, H), want_db=True)
         d_w_hh1 = wgrad(da1[B:], h1v[:-B])[0] if T > 1 else torch.zeros_like(w_hh1)
         dyp = d_ypre.view(T * B, HH)
         d_w1 = torch.mm(dyp.t(), h1v)
@@ -445,9 +452,22 @@ class GenRolloutFn(torch.autograd.Function):
         d_b2 = dov.sum(0)
         d_init = d_in0.sum(0).reshape(ctx.init_shape)
         return (d_g0, d_w_u, d_w_hh0, d_w_ih1, d_w_hh1, d_bias1, d_w1, d_b1, d_w2, d_b2, d_init,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def ctypes_byref(a):
     import ctypes
     return ctypes.cast(ctypes.pointer(a), ctypes.c_void_p)
+
+
+def dropout_keep_mask(T: int, B: int, H: int, p: float, seed: int) -> torch.Tensor:
+    """Host replica of the kernels' counter-based dropout mask (csrc/lstm_tile.h gmt_keep):
+    [T,B,H] float mask of 0 / 1/(1-p).  Used by the tests to feed the oracle the same mask."""
+    import numpy as np
+    idx = np.arange(T * B * H, dtype=np.uint64)
+    x = (idx + (np.uint64(seed & 0xFFFFFFFF) * np.uint64(0x9E3779B1))) & np.uint64(0xFFFFFFFF)
+    x = (x * np.uint64(747796405) + np.uint64(2891336453)) & np.uint64(0xFFFFFFFF)
+    w = (((x >> ((x >> np.uint64(28)) + np.uint64(4))) ^ x) * np.uint64(277803737)) & np.uint64(0xFFFFFFFF)
+    h = ((w >> np.uint64(22)) ^ w) & np.uint64(0xFFFFFFFF)
+    keep = (h >> np.uint64(8)) >= np.uint64(int(np.float32(p) * np.float32(16777216.0)))
+    return torch.from_numpy((keep.astype(np.float32) / np.float32(1.0 - p)).reshape(T, B, H))

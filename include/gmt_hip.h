@@ -169,7 +169,10 @@ typedef struct gmt_gen_fwd_args {
     float* u_all;           /* [T][B][8]  (in0,in1,in2, rem_x, rem_y, dist, angle, 0) */
     float* y_all;           /* [T][B][HH] head activation after LeakyReLU */
     float* oraw_all;        /* [T][B]     pre-softplus dt logit */
+    float* h0d_all;         /* [T][B][H]  layer-0 output after inter-layer dropout (only written when dropout_p > 0) */
     int T, B, H;
+    float dropout_p;        /* inter-layer dropout of nn.LSTM(dropout=0.1), RG.py:456; 0 = off (eval / parity) */
+    unsigned int seed;      /* mask = f(seed, t, row, unit): regenerated identically by the backward launch */
 } gmt_gen_fwd_args;
 int gmt_gen_rollout_fwd(const gmt_gen_fwd_args* args, hipStream_t stream);
 
@@ -191,6 +194,7 @@ typedef struct gmt_gen_bwd_args {
     float* d_o;              /* [T][B][3] out: gradient of the head's raw output */
     float* d_in0;            /* [B][3] out: gradient of the initial input, per row */
     int T, B, H;
+    float dropout_p; unsigned int seed;   /* as in the forward launch */
 } gmt_gen_bwd_args;
 int gmt_gen_rollout_bwd(const gmt_gen_bwd_args* args, hipStream_t stream);
 

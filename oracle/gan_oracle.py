@@ -172,7 +172,7 @@ def _g_head(P: Params, h):
 
 def generator_forward(P: Params, start, end, z, target: Tensor, tf_mask: Sequence[bool],
                       dropout_p: float = 0.0, gen: Optional[torch.Generator] = None,
-                      num_layers: int = 2) -> Tensor:
+                      num_layers: int = 2, dropout_mask: Optional[Tensor] = None) -> Tensor:
     """RG.py:508-604 with the per-step teacher-forcing coin (RG.py:588) given as
     tf_mask[t] == (coin_t < teacher_forcing_ratio).  Returns (B,T,3)."""
     B, T = start.shape[0], target.shape[1]
@@ -191,7 +191,8 @@ def generator_forward(P: Params, start, end, z, target: Tensor, tf_mask: Sequenc
                                    P[f'lstm.bias_ih_l{l}'], P[f'lstm.bias_hh_l{l}'])
             x = h[l]
             if l + 1 < num_layers:
-                x = _dropout(x, dropout_p, gen)
+                # dropout_mask (T,B,H), values 0 or 1/(1-p): an explicit inter-layer mask (tests)
+                x = x * dropout_mask[t] if dropout_mask is not None else _dropout(x, dropout_p, gen)
         out = _g_head(P, x)
         outs.append(out)
         pos = pos + out[:, :2]                                    # RG.py:585

@@ -145,3 +145,36 @@ def test_train_steps_mid_vs_reference():
 
 def test_train_steps_default_vs_reference():
     _replay('default', H.DEFAULT, 4, 8, H.DEFAULT_LENGTHS, False, 3e-4)
+
+
+@pytest.mark.parametrize('over,B,T', [(H.TINY, 6, 9), (H.MID, 8, 12), (H.DEFAULT, 4, 8)])
+def test_generator_fused_dropout_matches_oracle_with_same_mask(over, B, T):
+    """Inter-layer LSTM dropout (RG.py:456) is a counter-based mask inside the rollout kernels;
+    the oracle fed the host replica of that mask must give the same outputs and gradients."""
+    from generative_mouse_trajectories_amd import ops
+    gmt, cfg, G, D = build(over, 31, 32)
+    cfg.lstm_dropout = 0.25
+    seed = 12345
+    lengths = sorted(np.random.default_rng(0).integers(1, T + 1, B).tolist(), reverse=True)
+    b = H.batch_t(B, T, 33, lengths)
+    bd = dev_batch(b)
+    z = torch.randn(B, cfg.latent_dim, generator=torch.Generator().manual_seed(1))
+    mask_tf = [False, True] * (T // 2) + [False] * (T % 2)
+    w = torch.randn(B, T, 3, generator=torch.Generator().manual_seed(2))
+    G.zero_grad()
+    seq, _ = G(bd['starts'], bd['ends'], z.to(DEV), target_sequences=bd['sequences'], target_lengths=bd['lengths'],
+               tf_mask=mask_tf, dropout_seed=seed)
+    (seq * w.to(DEV)).sum().backward()
+    Hg = cfg.generator_hidden_dim
+    Bp = ops.pad_rows(B)
+    dm = ops.dropout_keep_mask(T, Bp, Hg, cfg.lstm_dropout, seed)[:, :B]
+    kept = float((dm > 0).double().mean())
+    assert abs(kept - 0.75) < 0.08, kept
+    # fp32 oracle: under teacher forcing the position lands (almost) exactly on the end point, where
+    # atan2 of the remaining offset is ill-conditioned; only the same fp32 arithmetic is comparable
+    Pg = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in G.state_dict().items()}
+    ref = O.generator_forward(Pg, b['starts'], b['ends'], z, b['sequences'], mask_tf, dropout_mask=dm)
+    H.assert_close(seq, ref.detach(), 5e-5, 'G fwd with dropout')
+    gr = torch.autograd.grad((ref * w).sum(), list(Pg.values()))
+    for (k, p), g_ref in zip(G.named_parameters(), gr):
+        H.assert_close(p.grad, g_ref, 2e-4, f'G bwd with dropout {k}')
