@@ -100,7 +100,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     pg = None
-    if world > 1:
+    force_dist = bool(os.environ.get('GMT_FORCE_DIST'))      # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
         pg = dist.group.WORLD
@@ -114,6 +115,9 @@ def main():
     torch.manual_seed(0)        # identical replicas on every rank
     G, D = gmt.Generator(cfg), gmt.Discriminator(cfg)
     tr = gmt.Trainer(G, D, cfg, dev, log_dir='/tmp/gmt_runs', world_size=world, process_group=pg)
+    if force_dist and world == 1:
+        tr.world_size = 2                   # take the all-reduce branch (a sum over one rank)
+        tr.g_optimizer.grad_scale = tr.d_optimizer.grad_scale = 1.0
     tr.epoch = cfg.teacher_forcing_decay_epochs     # steady state: teacher-forcing ratio 0 (fully autoregressive)
     G.train(); D.train()
     torch.manual_seed(1234 + rank)                  # per-rank noise
@@ -192,7 +196,7 @@ def main():
             except Exception as e:                                  # the baseline must never break the bench line
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

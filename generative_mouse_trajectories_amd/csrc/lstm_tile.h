@@ -61,33 +61,54 @@ __device__ __host__ __forceinline__ size_t gmt_pk_index(int w, int s4, int g, in
 // acc[g] += A(lds, [K][GMT_LDA]) * Wpk   for one wave; weights streamed from global/L2.
 // wpk points at this wave's packed block (K/8 groups of 4 gates x 64 lanes x float4).
 template <int NG>
+__device__ __forceinline__ void gmt_mma_group(f32x16 (&acc)[NG], const float (&a)[4], const float4 (&w)[NG])
+{
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], w[g].x, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], w[g].y, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], w[g].z, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], w[g].w, acc[g], 0, 0, 0);
+    }
+}
+
+template <int NG>
+__device__ __forceinline__ void gmt_stream_fetch(float4 (&w)[NG], float (&a)[4], const float4* __restrict__ wpk,
+                                                 const float* __restrict__ ap, int s4, int lane)
+{
+#pragma unroll
+    for (int g = 0; g < NG; ++g) w[g] = wpk[(s4 * NG + g) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = ap[(8 * s4 + 2 * j) * GMT_LDA];
+}
+
+// Two register buffers used in turn (no copies): the operands of k-group s4+1 are requested before
+// the 4*NG MFMAs of group s4 are issued, so an L2 round trip hides under a whole group.  The
+// scheduling fences keep the compiler from sinking the loads back down to their first use
+// (measured on MI355X: 34 -> 29 ns per MFMA, 28.5 being the register-only rate).
+template <int NG>
 __device__ __forceinline__ void gmt_mma_stream(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
                                                const float4* __restrict__ wpk, int K, int lane)
 {
     const int hi = lane >> 5, lo = lane & 31;
     const int ns4 = K >> 3;
-    float4 wn[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) wn[g] = wpk[g * 64 + lane];
+    const float* ap = lds_a + hi * GMT_LDA + lo;
+    float4 w0[NG], w1[NG];
+    float a0[4], a1[4];
+    gmt_stream_fetch<NG>(w0, a0, wpk, ap, 0, lane);
+    int s4 = 0;
 #pragma unroll 1
-    for (int s4 = 0; s4 < ns4; ++s4) {
-        float4 wc[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) wc[g] = wn[g];
-        if (s4 + 1 < ns4) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) wn[g] = wpk[((s4 + 1) * NG + g) * 64 + lane];
-        }
-        const float* ap = lds_a + (8 * s4 + hi) * GMT_LDA + lo;
-        const float a0 = ap[0], a1 = ap[2 * GMT_LDA], a2 = ap[4 * GMT_LDA], a3 = ap[6 * GMT_LDA];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wc[g].x, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wc[g].y, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, wc[g].z, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, wc[g].w, acc[g], 0, 0, 0);
-        }
+    for (; s4 + 1 < ns4; s4 += 2) {
+        gmt_stream_fetch<NG>(w1, a1, wpk, ap, s4 + 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        gmt_mma_group<NG>(acc, a0, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int sn = (s4 + 2 < ns4) ? s4 + 2 : ns4 - 1;       // last trip: an in-bounds reload, unused when ns4 is even
+        gmt_stream_fetch<NG>(w0, a0, wpk, ap, sn, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        gmt_mma_group<NG>(acc, a1, w1);
     }
+    if (ns4 & 1) gmt_mma_group<NG>(acc, a0, w0);
 }
 
 // Same contraction with the weights already in registers: wr[g][s], s = k-step (K/2 of them).
@@ -97,12 +118,23 @@ __device__ __forceinline__ void gmt_mma_resident(f32x16 (&acc)[NG], const float*
 {
     const int hi = lane >> 5, lo = lane & 31;
     const float* ap = lds_a + hi * GMT_LDA + lo;
+    // A fragments are fetched four k-steps ahead of their MFMAs (see gmt_mma_stream)
+    float an[4] = {ap[0], ap[2 * GMT_LDA], ap[4 * GMT_LDA], ap[6 * GMT_LDA]};
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const float a = ap[2 * s * GMT_LDA];
+    for (int s = 0; s < KS; s += 4) {
+        const float a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
+        if (s + 4 < KS) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[g][s], acc[g], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) an[j] = ap[2 * (s + 4 + j) * GMT_LDA];
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wr[g][s], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wr[g][s + 1], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, wr[g][s + 2], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, wr[g][s + 3], acc[g], 0, 0, 0);
     }
 }
 
