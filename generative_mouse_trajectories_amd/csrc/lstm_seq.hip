@@ -12,6 +12,12 @@
 // sweep; backward overwrites the gate buffer in place with d(pre-activation), which the
 // host then contracts with x / h_prev for the weight gradients (one large GEMM each).
 #include "lstm_tile.h"
+#include <type_traits>
+
+// k-steps of W_hh kept in LDS rather than registers by the H = 128 fused forward kernel
+#ifndef GMT_FWD_KL
+#define GMT_FWD_KL 16
+#endif
 
 namespace {
 
@@ -34,12 +40,25 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
     }
 }
 
+// Phase timing for tuning (scratch/phase_fwd.hip defines GMT_PHASE_TIMING and includes this file);
+// compiled out of the library.
+#ifdef GMT_PHASE_TIMING
+__device__ unsigned long long gmt_phase_ticks[8];
+#define GMT_PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[6] = {0, 0, 0, 0, 0, 0}
+#define GMT_PH(i) do { unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
+#define GMT_PH_DUMP do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) gmt_phase_ticks[i_] = ph_acc[i_]; } while (0)
+#else
+#define GMT_PH_DECL
+#define GMT_PH(i)
+#define GMT_PH_DUMP
+#endif
+
 // ------------------------------------------------------------------ forward
 // NW waves (H = 32 NW).  RES: recurrent weights resident in registers.  IX = I / H:
 //   IX = 0  the caller precomputed x W_ih^T + b into `pregates` (read from HBM);
 //   IX = 1,2 the input contraction runs inside the kernel, W_ih streamed from L2.
 // B must be a multiple of 32 (the host pads the batch), so there are no row guards.
-template <int NW, bool RES, int IX>
+template <int NW, bool RES, int IX, bool FULL>
 __global__ __launch_bounds__(NW * 64, 1)
 void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pregates,
                      const float* __restrict__ w_ih_pk, const float* __restrict__ w_hh_pk,
@@ -52,10 +71,15 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
     constexpr int I = (IX > 0 ? IX : 1) * H;
     constexpr int NT = NW * 64;
     extern __shared__ float smem[];
-    float* hT = smem;                                  // [2][H][LDA]
-    float* xT = smem + 2 * H * GMT_LDA;                // [2][I][LDA] (IX > 0 only)
+    // at H = 128 with the fused input contraction the last KL k-steps of W_hh live in LDS, not registers
+    constexpr int KL = (RES && NW == 4 && IX > 0) ? GMT_FWD_KL : 0;
+    constexpr int KR = KS - KL;
+    float* hT = smem;                                  // [H][LDA]  h_{t-1}, transposed (MFMA A operand)
+    float* xT = smem + H * GMT_LDA;                    // [I][LDA]  x_t, transposed (IX > 0 only)
+    float4* wl = reinterpret_cast<float4*>(smem + (H + (IX > 0 ? I : 0)) * GMT_LDA)
+                 + (size_t)(threadIdx.x >> 6) * (KL / 4) * 4 * 64;   // [NW][KL/4][4][64] float4
     __shared__ int s_len[GMT_TM];
-    __shared__ int s_maxlen;
+    __shared__ int s_maxlen, s_minlen;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,23 +88,28 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
     const int hi = lane >> 5, lo = lane & 31;
     const int col = wave * 32 + lo;                    // hidden unit of this lane
 
-    if (tid == 0) s_maxlen = 0;
+    if (tid == 0) { s_maxlen = 0; s_minlen = L; }
     __syncthreads();
     if (tid < GMT_TM) {
         int ln = lengths ? lengths[row0 + tid] : L;
         ln = ln < 1 ? 1 : (ln > L ? L : ln);           // RG.py:766 clamp(min=1)
         s_len[tid] = ln;
         atomicMax(&s_maxlen, ln);
+        atomicMin(&s_minlen, ln);
     }
-    for (int i = tid; i < 2 * H * GMT_LDA; i += NT) hT[i] = 0.0f;
+    for (int i = tid; i < H * GMT_LDA; i += NT) hT[i] = 0.0f;
     __syncthreads();
-    const int tmax = s_maxlen;                         // steps [tmax, L) are padding for the whole tile
+    const int tmax = __builtin_amdgcn_readfirstlane(s_maxlen);   // steps [tmax, L) are padding for the whole tile
+    const int tmin = __builtin_amdgcn_readfirstlane(s_minlen);   // steps [0, tmin) have every row active
 
     const float4* whh = reinterpret_cast<const float4*>(w_hh_pk) + ((size_t)dir * NW + wave) * (H / 8) * 4 * 64;
     const float4* wih = IX > 0 ? reinterpret_cast<const float4*>(w_ih_pk) + ((size_t)dir * NW + wave) * (I / 8) * 4 * 64
                                : nullptr;
-    float wr[4][RES ? KS : 1];
-    if constexpr (RES) gmt_load_resident<4, KS>(wr, whh, lane);
+    float wr[4][RES ? KR : 1];
+    if constexpr (RES) {
+        gmt_load_resident<4, KR>(wr, whh, lane);
+        for (int i = lane; i < (KL / 4) * 4 * 64; i += 64) wl[i] = whh[(KR / 4) * 4 * 64 + i];   // visible after the next barrier
+    }
 
     float bz[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (IX > 0) {
@@ -92,45 +121,52 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
 #pragma unroll
     for (int r = 0; r < 16; ++r) c[r] = 0.f;
 
-    // x tile staging: the 32 x I tile of step t is one contiguous run of x.  global ->
-    // registers early in the step, registers -> LDS (transposed) at its end, so the HBM
-    // latency hides under the MFMAs (T14 split).
+    // Step order (two barriers a step, single LDS buffers):
+    //   h-part   acc = bias + h_{t-1} W_hh^T   registers / LDS only: the global stores of the previous
+    //                                          cell update drain under it, nothing waits on them
+    //   x_store  x_t (registers) -> xT         every wave is past the previous x-part (barrier A)
+    //   barrier B
+    //   x-part   acc += x_t W_ih^T             W_ih streamed from L2
+    //   x_load   x_{t+1} -> registers          lands under the cell update and the next h-part
+    //   cell     gates, c, h -> hT, HBM        every wave is past the h-part (barrier B)
+    //   barrier A
     constexpr int XQ = I / 4;                          // float4 per row
     constexpr int XS = (GMT_TM * XQ) / NT;             // float4 per thread (= 4 * IX)
     float4 xs[IX > 0 ? XS : 1];
     auto x_load = [&](int t) {
         const float4* src = reinterpret_cast<const float4*>(x + ((size_t)t * B + row0) * I);
 #pragma unroll
-        for (int j = 0; j < XS; ++j) xs[j] = src[tid + j * NT];
+        for (int j = 0; j < XS; ++j) xs[j] = (src + j * NT)[tid];   // uniform base + one lane offset
     };
-    auto x_store = [&](int buf) {
+    auto x_store = [&]() {
+        // item tid + j*NT is row tid/XQ + j*(NT/XQ), float4 column tid%XQ: one LDS address, the
+        // j-th float4 sits j*(NT/XQ) floats further on
+        static_assert(NT % XQ == 0, "x tile staging assumes NT is a multiple of I/4");
+        float* d0 = xT + (size_t)(4 * (tid % XQ)) * GMT_LDA + tid / XQ;
 #pragma unroll
         for (int j = 0; j < XS; ++j) {
-            const int it = tid + j * NT;
-            const int rr = it / XQ, c4 = it % XQ;
-            float* d = xT + ((size_t)buf * I + 4 * c4) * GMT_LDA + rr;
+            float* d = d0 + j * (NT / XQ);
             d[0] = xs[j].x; d[GMT_LDA] = xs[j].y; d[2 * GMT_LDA] = xs[j].z; d[3 * GMT_LDA] = xs[j].w;
         }
     };
 
-    int cur = 0;
     if constexpr (IX > 0) {
-        if (tmax > 0) { x_load(dir ? tmax - 1 : 0); x_store(0); }
-        __syncthreads();
+        if (tmax > 0) x_load(dir ? tmax - 1 : 0);
     }
 
     const size_t lane_row = (size_t)row0 + 4 * hi;     // first row of this lane's accumulator rows
+    float* hs = hT + col * GMT_LDA + 4 * hi;           // this lane's 16 state slots (updated in place)
+    GMT_PH_DECL;
     for (int step = 0; step < tmax; ++step) {
         const int t = dir ? (tmax - 1 - step) : step;
+        GMT_PH(5);
         const size_t rs = ((size_t)dir * L + t) * B + lane_row;
         f32x16 acc[4];
         if constexpr (IX > 0) {
-            if (step + 1 < tmax) x_load(dir ? t - 1 : t + 1);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][r] = bz[g];
-            gmt_mma_stream<4>(acc, xT + (size_t)cur * I * GMT_LDA, wih, I, lane);
         } else {
             const float* pp = pregates + rs * (4 * H) + col;
 #pragma unroll
@@ -139,39 +175,67 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
                 for (int r = 0; r < 16; ++r)
                     acc[g][r] = pp[(size_t)((r & 3) + 8 * (r >> 2)) * (4 * H) + g * H];
         }
-        if constexpr (RES) gmt_mma_resident<4, KS>(acc, hT + (size_t)cur * H * GMT_LDA, wr, lane);
-        else gmt_mma_stream<4>(acc, hT + (size_t)cur * H * GMT_LDA, whh, H, lane);
+        if constexpr (RES) gmt_mma_resident<4, KS, KR>(acc, hT, wr, lane, wl);
+        else gmt_mma_stream<4>(acc, hT, whh, H, lane);
+        GMT_PH(1);
+        if constexpr (IX > 0) x_store();
+        GMT_PH(3);
+        __syncthreads();                               // B
+        GMT_PH(4);
+        if constexpr (IX > 0) {
+            gmt_mma_stream<4>(acc, xT, wih, I, lane);
+            // unconditional (the last step re-reads its own tile): a branch here splits the staging
+            // registers' live ranges and the compiler then waits for the loads on the spot
+            const int tn = (step + 1 < tmax) ? (dir ? t - 1 : t + 1) : t;
+            x_load(tn);
+            GMT_PH(0);
+        }
 
-        const float* ho = hT + (size_t)cur * H * GMT_LDA + col * GMT_LDA + 4 * hi;
-        float* hn = hT + (size_t)(cur ^ 1) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
         float* gp = gates ? gates + rs * (4 * H) + col : nullptr;
         float* cp = c_all ? c_all + rs * H + col : nullptr;
         float* hp = h_all ? h_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col : nullptr;
+        // the cell update; MASKED = some row of the tile is already past its length at step t
+        // (branch-free selects), otherwise no masks, no reads of the old state
+        auto cell = [&](auto masked) {
+            constexpr bool MASKED = decltype(masked)::value;
+            unsigned am = 0xffffu;
+            if constexpr (MASKED) {
+                am = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mr = (r & 3) + 8 * (r >> 2);     // row within the tile, minus 4*hi
-            const bool act = t < s_len[mr + 4 * hi];
-            const float ig = gmt_sigmoid(acc[0][r]);
-            const float fg = gmt_sigmoid(acc[1][r]);
-            const float gg = gmt_tanh(acc[2][r]);
-            const float og = gmt_sigmoid(acc[3][r]);
-            const float cn = fg * c[r] + ig * gg;
-            const float hv = og * gmt_tanh(cn);
-            c[r] = act ? cn : c[r];
-            hn[mr] = act ? hv : ho[mr];
-            if (gp) {
-                float* q = gp + (size_t)mr * (4 * H);
-                q[0] = act ? ig : 0.f; q[H] = act ? fg : 0.f; q[2 * H] = act ? gg : 0.f; q[3 * H] = act ? og : 0.f;
+                for (int r = 0; r < 16; ++r) am |= (unsigned)(t < s_len[(r & 3) + 8 * (r >> 2) + 4 * hi]) << r;
             }
-            if (cp) cp[(size_t)mr * H] = act ? cn : 0.f;
-            if (hp) hp[(size_t)mr * (ndir * H)] = act ? hv : 0.f;
-        }
-        if constexpr (IX > 0) {
-            if (step + 1 < tmax) x_store(cur ^ 1);
-        }
-        __syncthreads();
-        cur ^= 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = (r & 3) + 8 * (r >> 2);     // row within the tile, minus 4*hi
+                const float ig = gmt_sigmoid(acc[0][r]);
+                const float fg = gmt_sigmoid(acc[1][r]);
+                const float gg = gmt_tanh(acc[2][r]);
+                const float og = gmt_sigmoid(acc[3][r]);
+                const float cn = fg * c[r] + ig * gg;
+                const float hv = og * gmt_tanh(cn);
+                float* q = gp + (size_t)mr * (4 * H);
+                if constexpr (MASKED) {
+                    const bool act = (am >> r) & 1u;
+                    c[r] = act ? cn : c[r];
+                    hs[mr] = act ? hv : hs[mr];
+                    if (FULL || gp) { q[0] = act ? ig : 0.f; q[H] = act ? fg : 0.f; q[2 * H] = act ? gg : 0.f; q[3 * H] = act ? og : 0.f; }
+                    if (FULL || cp) cp[(size_t)mr * H] = act ? cn : 0.f;
+                    if (FULL || hp) hp[(size_t)mr * (ndir * H)] = act ? hv : 0.f;
+                } else {
+                    c[r] = cn;
+                    hs[mr] = hv;
+                    if (FULL || gp) { q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og; }   // FULL: no per-row branches
+                    if (FULL || cp) cp[(size_t)mr * H] = cn;
+                    if (FULL || hp) hp[(size_t)mr * (ndir * H)] = hv;
+                }
+            }
+        };
+        if (t < tmin) cell(std::false_type{});
+        else cell(std::true_type{});
+        GMT_PH(2);
+        __syncthreads();                               // A
     }
+    GMT_PH_DUMP;
 
     // padded tail of the whole tile: outputs are zero (pad_packed_sequence)
     if (h_all) {
@@ -182,7 +246,7 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
         }
     }
     if (h_final) {
-        const float* hl = hT + (size_t)cur * H * GMT_LDA + col * GMT_LDA + 4 * hi;
+        const float* hl = hs;
         float* hf = h_final + lane_row * (ndir * H) + dir * H + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -360,19 +424,21 @@ int launch_fwd(const float* x, const float* pregates, const float* w_ih_pk, cons
     constexpr bool RES = (NW <= 4);
     const int n_tiles = B / GMT_TM;
     const dim3 grid(n_tiles * ndir), block(NW * 64);
+    const bool full = gates && c_all && h_all;         // the training call: branch-free stores
 #define GMT_GO(IXV, LDSF)                                                                                         \
     {                                                                                                             \
-        const size_t lds = (size_t)(LDSF) * GMT_LDA * sizeof(float);                                              \
+        const size_t lds = (size_t)(LDSF) * GMT_LDA * sizeof(float)                                               \
+                           + ((RES && NW == 4 && IXV > 0) ? (size_t)NW * GMT_FWD_KL * 4 * 64 * sizeof(float) : 0); \
         if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;                                                   \
-        auto k = lstm_fwd_kernel<NW, RES, IXV>;                                                                   \
+        auto k = full ? lstm_fwd_kernel<NW, RES, IXV, true> : lstm_fwd_kernel<NW, RES, IXV, false>;               \
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return GMT_ERR_HIP;                                                                                   \
         hipLaunchKernelGGL(k, grid, block, lds, stream, x, pregates, w_ih_pk, w_hh_pk, bias, lengths, gates,      \
                            c_all, h_all, h_final, L, B, ndir, n_tiles);                                           \
     }
-    if (!x) GMT_GO(0, 2 * H)
-    else if (I == H) GMT_GO(1, 2 * H + 2 * H)
-    else if (I == 2 * H) GMT_GO(2, 2 * H + 4 * H)
+    if (!x) GMT_GO(0, H)
+    else if (I == H) GMT_GO(1, H + H)
+    else if (I == 2 * H) GMT_GO(2, H + 2 * H)
     else return GMT_ERR_UNSUPPORTED;
 #undef GMT_GO
     GMT_LAUNCH_CHECK();

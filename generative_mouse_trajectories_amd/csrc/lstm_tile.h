@@ -87,15 +87,25 @@ __device__ __forceinline__ void gmt_stream_fetch(float4 (&w)[NG], float (&a)[4],
 // scheduling fences keep the compiler from sinking the loads back down to their first use
 // (measured on MI355X: 34 -> 29 ns per MFMA, 28.5 being the register-only rate).
 template <int NG>
-__device__ __forceinline__ void gmt_mma_stream(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
-                                               const float4* __restrict__ wpk, int K, int lane)
+__device__ __forceinline__ void gmt_stream_wfetch(float4 (&w)[NG], const float4* __restrict__ wpk, int s4, int lane)
+{
+#pragma unroll
+    for (int g = 0; g < NG; ++g) w[g] = wpk[(s4 * NG + g) * 64 + lane];
+}
+
+// w0 already holds the weights of k-group 0 (gmt_stream_wfetch issued by the caller well before,
+// e.g. ahead of the element-wise phase of the previous step, so the first L2 round trip is hidden too).
+template <int NG>
+__device__ __forceinline__ void gmt_mma_stream_pf(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
+                                                  const float4* __restrict__ wpk, int K, int lane, float4 (&w0)[NG])
 {
     const int hi = lane >> 5, lo = lane & 31;
     const int ns4 = K >> 3;
     const float* ap = lds_a + hi * GMT_LDA + lo;
-    float4 w0[NG], w1[NG];
+    float4 w1[NG];
     float a0[4], a1[4];
-    gmt_stream_fetch<NG>(w0, a0, wpk, ap, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a0[j] = ap[2 * j * GMT_LDA];
     int s4 = 0;
 #pragma unroll 1
     for (; s4 + 1 < ns4; s4 += 2) {
@@ -104,37 +114,79 @@ __device__ __forceinline__ void gmt_mma_stream(f32x16 (&acc)[NG], const float* _
         gmt_mma_group<NG>(acc, a0, w0);
         __builtin_amdgcn_sched_barrier(0);
         const int sn = (s4 + 2 < ns4) ? s4 + 2 : ns4 - 1;       // last trip: an in-bounds reload, unused when ns4 is even
-        gmt_stream_fetch<NG>(w0, a0, wpk, ap, sn, lane);
+        gmt_stream_fetch<NG>(w0, a0, wpk, ap, sn, lane);        // (unconditional: a branch here makes every wait a full drain)
         __builtin_amdgcn_sched_barrier(0);
         gmt_mma_group<NG>(acc, a1, w1);
     }
     if (ns4 & 1) gmt_mma_group<NG>(acc, a0, w0);
 }
 
-// Same contraction with the weights already in registers: wr[g][s], s = k-step (K/2 of them).
-template <int NG, int KS>
-__device__ __forceinline__ void gmt_mma_resident(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
-                                                 const float (&wr)[NG][KS], int lane)
+// Two register buffers used in turn (no copies): the operands of k-group s4+1 are requested before
+// the 4*NG MFMAs of group s4 are issued, so an L2 round trip hides under a whole group.  The
+// scheduling fences keep the compiler from sinking the loads back down to their first use
+// (measured on MI355X: 34 -> 29 ns per MFMA, 28.5 being the register-only rate).
+template <int NG>
+__device__ __forceinline__ void gmt_mma_stream(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
+                                               const float4* __restrict__ wpk, int K, int lane)
 {
+    float4 w0[NG];
+    gmt_stream_wfetch<NG>(w0, wpk, 0, lane);
+    gmt_mma_stream_pf<NG>(acc, lds_a, wpk, K, lane, w0);
+}
+
+// Same contraction with the weights already on chip: wr[g][s], s = k-step, holds the first KR
+// k-steps in registers; the remaining KS - KR k-steps (NG == 4 only) sit in LDS in the packed fragment
+// order (wl = this wave's float4 block: [(KS-KR)/4][NG][64 lanes]), which takes 32 registers a lane
+// off the H = 128 kernels that would otherwise spill.  The A fragments (and the LDS weights) of the
+// next group of k-steps (>= 16 MFMAs) are read before the current group is issued; fences as in
+// gmt_mma_stream.
+template <int NG, int KS, int KR = KS>
+__device__ __forceinline__ void gmt_mma_resident(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
+                                                 const float (&wr)[NG][KR], int lane,
+                                                 const float4* __restrict__ wl = nullptr)
+{
+    constexpr int GS = (NG >= 4) ? 4 : (NG == 2 ? 8 : 16);      // k-steps per group
+    static_assert(KS % GS == 0 && KR % GS == 0, "K must be a multiple of the group size");
+    static_assert(KR == KS || (NG == 4 && GS == 4), "LDS-held tail only for the 4-gate form");
+    constexpr int NGRP = KS / GS, RGRP = KR / GS;
     const int hi = lane >> 5, lo = lane & 31;
     const float* ap = lds_a + hi * GMT_LDA + lo;
-    // A fragments are fetched four k-steps ahead of their MFMAs (see gmt_mma_stream)
-    float an[4] = {ap[0], ap[2 * GMT_LDA], ap[4 * GMT_LDA], ap[6 * GMT_LDA]};
+    float a[2][GS];
+    float4 wq[2][NG];
 #pragma unroll
-    for (int s = 0; s < KS; s += 4) {
-        const float a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
-        if (s + 4 < KS) {
+    for (int j = 0; j < GS; ++j) a[0][j] = ap[2 * j * GMT_LDA];
+    if constexpr (RGRP == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) an[j] = ap[2 * (s + 4 + j) * GMT_LDA];
+        for (int g = 0; g < NG; ++g) wq[0][g] = wl[g * 64 + lane];
+    }
+#pragma unroll
+    for (int grp = 0; grp < NGRP; ++grp) {
+        if (grp + 1 < NGRP) {
+#pragma unroll
+            for (int j = 0; j < GS; ++j) a[(grp + 1) & 1][j] = ap[2 * ((grp + 1) * GS + j) * GMT_LDA];
+            if (grp + 1 >= RGRP) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) wq[(grp + 1) & 1][g] = wl[((grp + 1 - RGRP) * NG + g) * 64 + lane];
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp < RGRP) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wr[g][s], acc[g], 0, 0, 0);
+            for (int j = 0; j < GS; ++j)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wr[g][s + 1], acc[g], 0, 0, 0);
+                for (int g = 0; g < NG; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][j], wr[g][grp * GS + j], acc[g], 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, wr[g][s + 2], acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, wr[g][s + 3], acc[g], 0, 0, 0);
+            for (int g = 0; g < NG; ++g) {
+                const float4 w = wq[grp & 1][g];
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][0], w.x, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][1], w.y, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][2], w.z, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][3], w.w, acc[g], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -142,6 +194,7 @@ __device__ __forceinline__ void gmt_mma_resident(f32x16 (&acc)[NG], const float*
 template <int NG, int KS>
 __device__ __forceinline__ void gmt_load_resident(float (&wr)[NG][KS], const float4* __restrict__ wpk, int lane)
 {
+    // (with an LDS-held tail, KS here is the register part KR; the tail is copied by the caller)
 #pragma unroll
     for (int s4 = 0; s4 < KS / 4; ++s4)
 #pragma unroll
