@@ -18,6 +18,10 @@
 #ifndef GMT_FWD_KL
 #define GMT_FWD_KL 16
 #endif
+// the same for W_hh^T in the H = 128 backward kernel
+#ifndef GMT_BWD_KL
+#define GMT_BWD_KL 64
+#endif
 
 namespace {
 
@@ -261,7 +265,9 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
 // Per step: d(pre-activation) from the saved gates -> written over the gate buffer and to
 // LDS (transposed) -> dh_prev = da W_hh as an MFMA contraction over K = 4H with W_hh
 // resident in registers (or streamed).
-template <int NW, bool RES>
+// PLAIN: the ordinary training call (no extra adjoints, no extra outputs, d(pre-activation) in place):
+// no per-row pointer tests in the element-wise phase.
+template <int NW, bool RES, bool PLAIN>
 __global__ __launch_bounds__(NW * 64, 1)
 void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, const float* __restrict__ c_all,
                      const float* __restrict__ w_hh_pkT, const int* __restrict__ lengths,
@@ -276,11 +282,14 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
 {
     constexpr int H = NW * 32;
     constexpr int KS = 2 * H;                          // k-steps over K = 4H
-    constexpr int NT = NW * 64;
+    // at H = 128 the last KL k-steps of W_hh^T live in LDS, not registers (the prefetch registers need the room)
+    constexpr int KL = (RES && NW == 4) ? GMT_BWD_KL : 0;
+    constexpr int KR = KS - KL;
     extern __shared__ float smem[];
     float* daT = smem;                                 // [4H][LDA]
+    float4* wl = reinterpret_cast<float4*>(smem + 4 * H * GMT_LDA) + (size_t)(threadIdx.x >> 6) * (KL / 4) * 64;
     __shared__ int s_len[GMT_TM];
-    __shared__ int s_maxlen;
+    __shared__ int s_maxlen, s_minlen;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -289,20 +298,25 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
     const int hi = lane >> 5, lo = lane & 31;
     const int col = wave * 32 + lo;
 
-    if (tid == 0) s_maxlen = 0;
+    if (tid == 0) { s_maxlen = 0; s_minlen = L; }
     __syncthreads();
     if (tid < GMT_TM) {
         int ln = lengths ? lengths[row0 + tid] : L;
         ln = ln < 1 ? 1 : (ln > L ? L : ln);
         s_len[tid] = ln;
         atomicMax(&s_maxlen, ln);
+        atomicMin(&s_minlen, ln);
     }
     __syncthreads();
-    const int tmax = s_maxlen;
+    const int tmax = __builtin_amdgcn_readfirstlane(s_maxlen);
+    const int tmin = __builtin_amdgcn_readfirstlane(s_minlen);
 
     const float4* wT = reinterpret_cast<const float4*>(w_hh_pkT) + ((size_t)dir * NW + wave) * (4 * H / 8) * 64;
-    float wr[1][RES ? KS : 1];
-    if constexpr (RES) gmt_load_resident<1, KS>(wr, wT, lane);
+    float wr[1][RES ? KR : 1];
+    if constexpr (RES) {
+        gmt_load_resident<1, KR>(wr, wT, lane);
+        for (int i = lane; i < (KL / 4) * 64; i += 64) wl[i] = wT[(KR / 4) * 64 + i];   // visible after the first barrier of the sweep
+    }
 
     const size_t lane_row = (size_t)row0 + 4 * hi;
     float dh[16], dc[16];
@@ -313,100 +327,126 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
         dc[r] = 0.f;
     }
 
-    // Software pipeline: the saved activations of the NEXT step are fetched into registers
-    // right after the barrier that opens the MFMA phase, so their HBM latency and transfer
-    // run under the contraction (the element-wise phase then starts with its operands in
-    // registers).  c_t is carried from the previous step's c_prev fetch.
+    // Software pipeline: the saved activations of the NEXT step are fetched into registers during
+    // the MFMA phase - one accumulator row (6 loads) ahead of each group of 16 MFMAs, so neither
+    // their issue slots nor their HBM latency are exposed.  c_t is carried from the previous
+    // step's c_prev fetch.
     float pg[4][16], pcp[16], pdy[16], cn_c[16];
-    auto prefetch = [&](int t) {
+    auto prefetch_row = [&](int t, int r) {
         const int tp = dir ? t + 1 : t - 1;
         const bool tp_ok = (tp >= 0) && (tp < L);
         const size_t rs = ((size_t)dir * L + t) * B + lane_row;
-        const float* gp = gates + rs * (4 * H) + col;
-        const float* cp_p = c_all + (((size_t)dir * L + (tp_ok ? tp : t)) * B + lane_row) * H + col;
-        const float* dy_p = dh_all ? dh_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col : nullptr;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mr = (r & 3) + 8 * (r >> 2);
-            const float* q = gp + (size_t)mr * (4 * H);
-            pg[0][r] = q[0]; pg[1][r] = q[H]; pg[2][r] = q[2 * H]; pg[3][r] = q[3 * H];
-            pcp[r] = tp_ok ? cp_p[(size_t)mr * H] : 0.f;
-            pdy[r] = dy_p ? dy_p[(size_t)mr * (ndir * H)] : 0.f;
-        }
+        const int mr = (r & 3) + 8 * (r >> 2);
+        const float* q = gates + (rs + mr) * (4 * H) + col;
+        pg[0][r] = q[0]; pg[1][r] = q[H]; pg[2][r] = q[2 * H]; pg[3][r] = q[3 * H];
+        const float cpv = c_all[(((size_t)dir * L + (tp_ok ? tp : t)) * B + lane_row + mr) * H + col];
+        pcp[r] = tp_ok ? cpv : 0.f;
+        pdy[r] = dh_all ? dh_all[((size_t)t * B + lane_row + mr) * (ndir * H) + dir * H + col] : 0.f;
     };
     if (tmax > 0) {
         const int t0 = dir ? 0 : tmax - 1;
-        prefetch(t0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prefetch_row(t0, r);
         const float* cn_p = c_all + (((size_t)dir * L + t0) * B + lane_row) * H + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) cn_c[r] = cn_p[(size_t)((r & 3) + 8 * (r >> 2)) * H];
     }
 
     // forward visited t in order (dir 0: 0..tmax-1, dir 1: tmax-1..0); walk it backwards
+    GMT_PH_DECL;
     for (int step = tmax - 1; step >= 0; --step) {
         const int t = dir ? (tmax - 1 - step) : step;
         const int tp = dir ? t + 1 : t - 1;            // the step the forward pass visited before t
+        GMT_PH(5);
         const size_t rs = ((size_t)dir * L + t) * B + lane_row;
-        float* wp = (da_out ? da_out : gates) + rs * (4 * H) + col;
-        float* dct_p = dct_out ? dct_out + rs * H + col : nullptr;
-        float* dht_p = dht_out ? dht_out + rs * H + col : nullptr;
-        const float* ge_p = dgates_extra ? dgates_extra + rs * (4 * H) + col : nullptr;
-        const float* ce_p = dc_extra ? dc_extra + rs * H + col : nullptr;
+        float* wp = ((!PLAIN && da_out) ? da_out : gates) + rs * (4 * H) + col;
+        float* dct_p = (!PLAIN && dct_out) ? dct_out + rs * H + col : nullptr;
+        float* dht_p = (!PLAIN && dht_out) ? dht_out + rs * H + col : nullptr;
+        const float* ge_p = (!PLAIN && dgates_extra) ? dgates_extra + rs * (4 * H) + col : nullptr;
+        const float* ce_p = (!PLAIN && dc_extra) ? dc_extra + rs * H + col : nullptr;
+        float* dl = daT + col * GMT_LDA + 4 * hi;      // this lane's slots of the transposed da tile
         f32x16 acc[1];
+        // MASKED = some row of the tile is past its length at t, or has no earlier step: selects,
+        // no branches; otherwise every row is live and has a predecessor (or tp < 0 for all)
+        auto sweep = [&](auto masked) {
+            constexpr bool MASKED = decltype(masked)::value;
+            unsigned am = 0xffffu, pm = 0xffffu;
+            if constexpr (MASKED) {
+                am = 0; pm = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mr = (r & 3) + 8 * (r >> 2);
-            const int m = mr + 4 * hi;
-            const int ln = s_len[m];
-            const bool act = t < ln;
-            float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f, dct_s = 0.f, dht_s = 0.f;
-            if (act) {
+                for (int r = 0; r < 16; ++r) {
+                    const int ln = s_len[(r & 3) + 8 * (r >> 2) + 4 * hi];
+                    am |= (unsigned)(t < ln) << r;
+                    pm |= (unsigned)(dir ? (tp < ln) : (tp >= 0)) << r;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = (r & 3) + 8 * (r >> 2);
+                const bool act = !MASKED || ((am >> r) & 1u);
+                const bool has_prev = !MASKED || ((pm >> r) & 1u);
                 const float ig = pg[0][r], fg = pg[1][r], gg = pg[2][r], og = pg[3][r];
                 const float cn = cn_c[r];
-                const bool has_prev = dir ? (tp < ln) : (tp >= 0);
                 const float cp = has_prev ? pcp[r] : 0.f;
                 const float dht = dh[r] + pdy[r];
                 const float tc = gmt_tanh(cn);
                 float dog = dht * tc;
                 float dct = dc[r] + dht * og * (1.f - tc * tc);
-                if (ce_p) dct += ce_p[(size_t)mr * H];
+                if (!PLAIN && ce_p) dct += ce_p[(size_t)mr * H];
                 float dig = dct * gg, dgg = dct * ig, dfg = dct * cp;
-                if (ge_p) {
+                if (!PLAIN && ge_p) {
                     const float* ep = ge_p + (size_t)mr * (4 * H);
                     dig += ep[0]; dfg += ep[H]; dgg += ep[2 * H]; dog += ep[3 * H];
                 }
-                dc[r] = dct * fg;
-                dct_s = dct; dht_s = dht;
-                dai = dig * ig * (1.f - ig);
-                daf = dfg * fg * (1.f - fg);
-                dag = dgg * (1.f - gg * gg);
-                dao = dog * og * (1.f - og);
-                acc[0][r] = 0.f;                       // dh_prev = da W_hh only
-            } else {
-                acc[0][r] = dh[r];                     // frozen row: state passes through
+                dc[r] = act ? dct * fg : dc[r];
+                const float dai = act ? dig * ig * (1.f - ig) : 0.f;
+                const float daf = act ? dfg * fg * (1.f - fg) : 0.f;
+                const float dag = act ? dgg * (1.f - gg * gg) : 0.f;
+                const float dao = act ? dog * og * (1.f - og) : 0.f;
+                acc[0][r] = act ? 0.f : dh[r];         // live row: dh_prev = da W_hh only; frozen row: state passes through
+                cn_c[r] = pcp[r];                      // c of the step processed next
+                // d(pre-activation) replaces the gates (zero at padded steps: the weight-gradient GEMM reads it)
+                float* w = wp + (size_t)mr * (4 * H);
+                w[0] = dai; w[H] = daf; w[2 * H] = dag; w[3 * H] = dao;
+                if (!PLAIN && dct_p) dct_p[(size_t)mr * H] = act ? dct : 0.f;
+                if (!PLAIN && dht_p) dht_p[(size_t)mr * H] = act ? dht : 0.f;
+                dl[0 * H * GMT_LDA + mr] = dai;
+                dl[1 * H * GMT_LDA + mr] = daf;
+                dl[2 * H * GMT_LDA + mr] = dag;
+                dl[3 * H * GMT_LDA + mr] = dao;
             }
-            cn_c[r] = pcp[r];                          // c of the step processed next
-            // d(pre-activation) replaces the gates (zero at padded steps: the weight-gradient GEMM reads it)
-            float* w = wp + (size_t)mr * (4 * H);
-            w[0] = dai; w[H] = daf; w[2 * H] = dag; w[3 * H] = dao;
-            if (dct_p) dct_p[(size_t)mr * H] = dct_s;
-            if (dht_p) dht_p[(size_t)mr * H] = dht_s;
-            daT[(0 * H + col) * GMT_LDA + m] = dai;
-            daT[(1 * H + col) * GMT_LDA + m] = daf;
-            daT[(2 * H + col) * GMT_LDA + m] = dag;
-            daT[(3 * H + col) * GMT_LDA + m] = dao;
-        }
+        };
+        if (dir ? (t + 1 < tmin) : (t < tmin)) sweep(std::false_type{});
+        else sweep(std::true_type{});
+        GMT_PH(0);
         __syncthreads();
-        if (step > 0) prefetch(dir ? t + 1 : t - 1);
-        if constexpr (RES) gmt_mma_resident<1, KS>(acc, daT, wr, lane);
-        else gmt_mma_stream<1>(acc, daT, wT, 4 * H, lane);
+        GMT_PH(1);
+        // next step's operands (the last step re-reads its own: no branch, no split live ranges)
+        const int tn = (step > 0) ? (dir ? t + 1 : t - 1) : t;
+        if constexpr (RES) {
+            gmt_mma_resident<1, KS, KR>(acc, daT, wr, lane, wl,
+                                        [&](int grp) {
+                                            // KS/8 groups a step: spread the 16 rows evenly over them
+#pragma unroll
+                                            for (int r = 0; r < 16; ++r)
+                                                if ((r * (KS / 8)) / 16 == grp) prefetch_row(tn, r);
+                                        });
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) prefetch_row(tn, r);
+            GMT_PH(2);
+            gmt_mma_stream<1>(acc, daT, wT, 4 * H, lane);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = acc[0][r];
+        GMT_PH(3);
         __syncthreads();
+        GMT_PH(4);
     }
+    GMT_PH_DUMP;
     // steps [tmax, L) of the tile are padding: zero their d(pre-activation)
     for (int t = tmax; t < L; ++t) {
-        float* gp = (da_out ? da_out : gates) + (((size_t)dir * L + t) * B + lane_row) * (4 * H) + col;
+        float* gp = ((!PLAIN && da_out) ? da_out : gates) + (((size_t)dir * L + t) * B + lane_row) * (4 * H) + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float* q = gp + (size_t)((r & 3) + 8 * (r >> 2)) * (4 * H);
@@ -453,9 +493,10 @@ int launch_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const in
     constexpr int H = NW * 32;
     constexpr bool RES = (NW <= 4);
     const int n_tiles = B / GMT_TM;
-    const size_t lds = (size_t)(4 * H) * GMT_LDA * sizeof(float);
+    const size_t lds = (size_t)(4 * H) * GMT_LDA * sizeof(float) + ((RES && NW == 4) ? (size_t)NW * GMT_BWD_KL * 64 * sizeof(float) : 0);
     if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;
-    auto k = lstm_bwd_kernel<NW, RES>;
+    const bool plain = !dgates_extra && !dc_extra && !da_out && !dct_out && !dht_out;
+    auto k = plain ? lstm_bwd_kernel<NW, RES, true> : lstm_bwd_kernel<NW, RES, false>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GMT_ERR_HIP;
     hipLaunchKernelGGL(k, dim3(n_tiles * ndir), dim3(NW * 64), lds, stream, gates, c_all, w_hh_pkT, lengths,

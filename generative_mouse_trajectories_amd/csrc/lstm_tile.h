@@ -136,57 +136,77 @@ __device__ __forceinline__ void gmt_mma_stream(f32x16 (&acc)[NG], const float* _
 
 // Same contraction with the weights already on chip: wr[g][s], s = k-step, holds the first KR
 // k-steps in registers; the remaining KS - KR k-steps (NG == 4 only) sit in LDS in the packed fragment
-// order (wl = this wave's float4 block: [(KS-KR)/4][NG][64 lanes]), which takes 32 registers a lane
+// order (wl = this wave's float4 block: [(KS-KR)/4][NG][64 lanes]), which takes registers
 // off the H = 128 kernels that would otherwise spill.  The A fragments (and the LDS weights) of the
-// next group of k-steps (>= 16 MFMAs) are read before the current group is issued; fences as in
+// next group of k-steps (>= 8 MFMAs) are read before the current group is issued; fences as in
 // gmt_mma_stream.
-template <int NG, int KS, int KR = KS>
+struct gmt_no_side { __device__ __forceinline__ void operator()(int) const {} };
+
+// `side(grp)` is called once per group, ahead of that group's MFMAs, grp a compile-time constant
+// after unrolling: the caller uses it to issue independent global loads (e.g. the next step's
+// operands, one row per group) so that their issue slots hide under the matrix pipe.
+template <int NG, int KS, int KR = KS, class Side = gmt_no_side>
 __device__ __forceinline__ void gmt_mma_resident(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
                                                  const float (&wr)[NG][KR], int lane,
-                                                 const float4* __restrict__ wl = nullptr)
+                                                 const float4* __restrict__ wl = nullptr, Side side = Side())
 {
-    constexpr int GS = (NG >= 4) ? 4 : (NG == 2 ? 8 : 16);      // k-steps per group
+    constexpr int GS = (NG >= 4) ? 4 : 8;                       // k-steps per group (>= 8 MFMAs)
+    constexpr int GQ = GS / 4;                                  // float4 of packed weights per gate and group
     static_assert(KS % GS == 0 && KR % GS == 0, "K must be a multiple of the group size");
-    static_assert(KR == KS || (NG == 4 && GS == 4), "LDS-held tail only for the 4-gate form");
     constexpr int NGRP = KS / GS, RGRP = KR / GS;
     const int hi = lane >> 5, lo = lane & 31;
     const float* ap = lds_a + hi * GMT_LDA + lo;
     float a[2][GS];
-    float4 wq[2][NG];
+    float4 wq[2][GQ][NG];
+    // one-gate form: a second accumulator takes the odd k-steps, so consecutive MFMAs are independent
+    f32x16 alt;
+    if constexpr (NG == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) alt[r] = 0.f;
+    }
+    auto tail_fetch = [&](int grp) {                            // grp >= RGRP
+#pragma unroll
+        for (int q = 0; q < GQ; ++q)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) wq[grp & 1][q][g] = wl[(((grp - RGRP) * GQ + q) * NG + g) * 64 + lane];
+    };
 #pragma unroll
     for (int j = 0; j < GS; ++j) a[0][j] = ap[2 * j * GMT_LDA];
-    if constexpr (RGRP == 0) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) wq[0][g] = wl[g * 64 + lane];
-    }
+    if constexpr (RGRP == 0) tail_fetch(0);
 #pragma unroll
     for (int grp = 0; grp < NGRP; ++grp) {
         if (grp + 1 < NGRP) {
 #pragma unroll
             for (int j = 0; j < GS; ++j) a[(grp + 1) & 1][j] = ap[2 * ((grp + 1) * GS + j) * GMT_LDA];
-            if (grp + 1 >= RGRP) {
-#pragma unroll
-                for (int g = 0; g < NG; ++g) wq[(grp + 1) & 1][g] = wl[((grp + 1 - RGRP) * NG + g) * 64 + lane];
-            }
+            if (grp + 1 >= RGRP) tail_fetch(grp + 1);
         }
+        side(grp);
         __builtin_amdgcn_sched_barrier(0);
-        if (grp < RGRP) {
 #pragma unroll
-            for (int j = 0; j < GS; ++j)
-#pragma unroll
-                for (int g = 0; g < NG; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][j], wr[g][grp * GS + j], acc[g], 0, 0, 0);
-        } else {
+        for (int j = 0; j < GS; ++j) {
+            float w[NG];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                const float4 w = wq[grp & 1][g];
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][0], w.x, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][1], w.y, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][2], w.z, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][3], w.w, acc[g], 0, 0, 0);
+                if (grp < RGRP) w[g] = wr[g][grp * GS + j];
+                else {
+                    const float4 v = wq[grp & 1][j / 4][g];
+                    w[g] = (j & 3) == 0 ? v.x : (j & 3) == 1 ? v.y : (j & 3) == 2 ? v.z : v.w;
+                }
+            }
+            if constexpr (NG == 1) {
+                if (j & 1) alt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][j], w[0], alt, 0, 0, 0);
+                else acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][j], w[0], acc[0], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][j], w[g], acc[g], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (NG == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] += alt[r];
     }
 }
 
