@@ -14,101 +14,181 @@
 
 namespace {
 
-constexpr int WG_TN = 256, WG_TI = 128, WG_RC = 16;     // tile n, tile i, rows per chunk
-constexpr int WG_LDA = WG_TN + 4, WG_LDX = WG_TI + 4;   // LDS pitches (floats): +4 keeps float4 alignment
+constexpr int WG_RC = 16;                               // rows per chunk
 
+// NB: 32-wide n blocks per wave (tile n = 128 NB), QB: 32-wide i blocks (tile i = 32 QB).
+//   <2, 4>  256 x 128  the recurrent weights (N = 4H, I = H / 2H)
+//   <1, 4>  128 x 128  N = 64 / 128 (feature encoder, output heads); columns n >= N read as zero
+//   <*, 1>  x 32       skinny inputs (I <= 32, any row pitch: scalar guarded loads), HBM-bound
+// Workgroups of one row slab sit on the same XCD (blockIdx % 8), so the dA / X rows they share are
+// fetched into that XCD's L2 once.
+template <int NB, int QB>
 __global__ __launch_bounds__(256, 2)
 void wgrad_kernel(const float* __restrict__ dA, long long lda, const float* __restrict__ X, long long ldx,
                   float* __restrict__ slab, float* __restrict__ db_slab, int N, int I, long long R, int ksplit)
 {
-    __shared__ float sA[2][WG_RC][WG_LDA];
-    __shared__ float sX[2][WG_RC][WG_LDX];
+    constexpr int TN = 128 * NB, TI = 32 * QB;
+    constexpr int LDA_ = TN + 4, LDX_ = TI + 4;         // LDS pitches (floats): +4 keeps float4 alignment
+    constexpr int AC4 = TN / 4, ARG = 256 / AC4, AJ = WG_RC / ARG;   // A staging: float4 columns, row groups, float4 per thread
+    constexpr bool XV = (QB == 4);                      // X staged as float4 (aligned, I % 128 == 0)
+    constexpr int XC4 = TI / 4, XRG = 256 / XC4, XJ = XV ? WG_RC / XRG : 1;
+    __shared__ float sA[2][WG_RC][LDA_];
+    __shared__ float sX[2][WG_RC][LDX_];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lo = lane & 31;
-    const int n_tiles = N / WG_TN, i_tiles = I / WG_TI;
+    const int n_tiles = (N + TN - 1) / TN, i_tiles = (I + TI - 1) / TI;
+    // blockIdx = xcd + 8 * (tile + tiles * ks_group), ks = 8 * ks_group + xcd
     int bid = blockIdx.x;
+    const int xcd = bid & 7; bid >>= 3;
     const int it = bid % i_tiles; bid /= i_tiles;
     const int nt = bid % n_tiles; bid /= n_tiles;
-    const int ks = bid;
+    const int ks = bid * 8 + xcd;
+    if (ks >= ksplit) return;
     const long long n_chunks = R / WG_RC;
     const long long cpk = (n_chunks + ksplit - 1) / ksplit;
     const long long c0 = (long long)ks * cpk;
     long long c1 = c0 + cpk; if (c1 > n_chunks) c1 = n_chunks;
 
-    // staging map: A chunk = 16 rows x 64 float4, X chunk = 16 rows x 32 float4
-    const int a_c4 = tid & 63, a_r0 = tid >> 6;         // rows a_r0 + 4j, j = 0..3
-    const int x_c4 = tid & 31, x_r0 = tid >> 5;         // rows x_r0 + 8j, j = 0..1
-    const float* gA = dA + (long long)nt * WG_TN + 4 * a_c4;
-    const float* gX = X + (long long)it * WG_TI + 4 * x_c4;
-    float4 ra[WG_RC / 4], rx[WG_RC / 8];
+    const int a_c4 = tid % AC4, a_r0 = tid / AC4;       // rows a_r0 + ARG * j
+    const bool a_ok = nt * TN + 4 * a_c4 < N;           // N % 4 == 0: whole float4 in or out
+    // X: float4 map (x_c4, rows x_r0 + XRG * j) or scalar map (2 elements: rows tid/32 and tid/32 + 8, column tid%32)
+    const int x_c4 = tid % XC4, x_r0 = tid / XC4;
+    const int xs_c = tid & 31, xs_r = tid >> 5;
+    const bool xs_ok = it * TI + xs_c < I;
+    // addressing: one uniform base per chunk (scalar registers) + per-thread 32-bit element offsets
+    // that never change (a 16-row chunk spans < 2^31 elements)
+    const float* tA = dA + (long long)nt * TN;
+    const float* tX = X + (long long)it * TI;
+    unsigned offA[AJ], offX[XV ? XJ : 2];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) offA[j] = (unsigned)((a_r0 + ARG * j) * lda + 4 * a_c4);
+    if constexpr (XV) {
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) offX[j] = (unsigned)((x_r0 + XRG * j) * ldx + 4 * x_c4);
+    } else {
+        offX[0] = (unsigned)(xs_r * ldx + xs_c);
+        offX[1] = (unsigned)((xs_r + 8) * ldx + xs_c);
+    }
+
+    struct Stage { float4 ra[AJ]; float4 rx[XV ? XJ : 1]; };
     float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto g_load = [&](long long c) {
-        const long long r = c * WG_RC;
+    auto g_load = [&](Stage& st, long long c) {
+        const float* bA = tA + c * WG_RC * lda;
+        const float* bX = tX + c * WG_RC * ldx;
 #pragma unroll
-        for (int j = 0; j < WG_RC / 4; ++j) ra[j] = *reinterpret_cast<const float4*>(gA + (r + a_r0 + 4 * j) * lda);
+        for (int j = 0; j < AJ; ++j)
+            st.ra[j] = a_ok ? *reinterpret_cast<const float4*>(bA + offA[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (XV) {
 #pragma unroll
-        for (int j = 0; j < WG_RC / 8; ++j) rx[j] = *reinterpret_cast<const float4*>(gX + (r + x_r0 + 8 * j) * ldx);
-    };
-    auto s_store = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < WG_RC / 4; ++j) {
-            *reinterpret_cast<float4*>(&sA[buf][a_r0 + 4 * j][4 * a_c4]) = ra[j];
-            colsum.x += ra[j].x; colsum.y += ra[j].y; colsum.z += ra[j].z; colsum.w += ra[j].w;
+            for (int j = 0; j < XJ; ++j) st.rx[j] = *reinterpret_cast<const float4*>(bX + offX[j]);
+        } else {
+            st.rx[0].x = xs_ok ? bX[offX[0]] : 0.f;
+            st.rx[0].y = xs_ok ? bX[offX[1]] : 0.f;
         }
+    };
+    auto s_store = [&](Stage& st, int buf) {
 #pragma unroll
-        for (int j = 0; j < WG_RC / 8; ++j) *reinterpret_cast<float4*>(&sX[buf][x_r0 + 8 * j][4 * x_c4]) = rx[j];
+        for (int j = 0; j < AJ; ++j) {
+            *reinterpret_cast<float4*>(&sA[buf][a_r0 + ARG * j][4 * a_c4]) = st.ra[j];
+            colsum.x += st.ra[j].x; colsum.y += st.ra[j].y; colsum.z += st.ra[j].z; colsum.w += st.ra[j].w;
+        }
+        if constexpr (XV) {
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) *reinterpret_cast<float4*>(&sX[buf][x_r0 + XRG * j][4 * x_c4]) = st.rx[j];
+        } else {
+            sX[buf][xs_r][xs_c] = st.rx[0].x;
+            sX[buf][xs_r + 8][xs_c] = st.rx[0].y;
+        }
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[NB][QB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NB; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < QB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    int cur = 0;
-    if (c0 < c1) { g_load(c0); s_store(0); }
-    __syncthreads();
-    for (long long c = c0; c < c1; ++c) {
-        if (c + 1 < c1) g_load(c + 1);
-        const float* pa = &sA[cur][hi][wave * 64 + lo];
-        const float* px = &sX[cur][hi][lo];
+    auto compute = [&](int buf) {
+        const float* pa = &sA[buf][hi][wave * (32 * NB) + lo];
+        const float* px = &sX[buf][hi][lo];
 #pragma unroll
         for (int s = 0; s < WG_RC / 2; ++s) {
-            const float a0 = pa[2 * s * WG_LDA], a1 = pa[2 * s * WG_LDA + 32];
-            float b[4];
+            float av[NB], bv[QB];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] = px[2 * s * WG_LDX + 32 * q];
+            for (int a = 0; a < NB; ++a) av[a] = pa[2 * s * LDA_ + 32 * a];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[q], acc[0][q], 0, 0, 0);
-                acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[q], acc[1][q], 0, 0, 0);
-            }
+            for (int q = 0; q < QB; ++q) bv[q] = px[2 * s * LDX_ + 32 * q];
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+#pragma unroll
+                for (int a = 0; a < NB; ++a)
+                    acc[a][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[q], acc[a][q], 0, 0, 0);
         }
-        if (c + 1 < c1) s_store(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    };
+
+    // Two register stages in turn: chunk c+2 is requested while chunk c is contracted and chunk c+1
+    // (requested one trip earlier) moves registers -> LDS, so a row chunk has two trips (~3 us) to
+    // arrive from HBM.  Indices past the slab are clamped (a harmless re-read), never branched on.
+    Stage s0, s1;
+    const long long cl = c1 - 1;
+    if (c0 < c1) {
+        g_load(s0, c0);
+        s_store(s0, 0);
+        g_load(s0, c0 + 1 < c1 ? c0 + 1 : cl);
     }
-    // partial tile -> slab[ks][n][i]
-    float* out = slab + ((long long)ks * N + (long long)nt * WG_TN + wave * 64) * I + (long long)it * WG_TI + lo;
+    __syncthreads();
+    long long c = c0;
+    for (; c + 1 < c1; c += 2) {                        // LDS[0] = chunk c, s0 = chunk c+1
+        g_load(s1, c + 2 < c1 ? c + 2 : cl);
+        compute(0);
+        s_store(s0, 1);
+        __syncthreads();
+        g_load(s0, c + 3 < c1 ? c + 3 : cl);
+        compute(1);
+        if (c + 2 < c1) s_store(s1, 0);                 // (a clamped re-read must not reach the column sums)
+        __syncthreads();
+    }
+    if (c < c1) compute(0);                             // odd tail
+    // partial tile -> slab[ks][n][i]   (rows n >= N / columns i >= I of an edge tile are dropped)
+    {
+        const int n0 = nt * TN + wave * (32 * NB), i0 = it * TI + lo;
+        float* out = slab + ((long long)ks * N + n0) * I + i0;
+        const bool whole = (nt + 1) * TN <= N && (it + 1) * TI <= I;
+        if (whole) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < NB; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < QB; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                out[(long long)(a * 32 + gmt_acc_row(r, lane)) * I + 32 * q] = acc[a][q][r];
+                    for (int r = 0; r < 16; ++r)
+                        out[(long long)(a * 32 + gmt_acc_row(r, lane)) * I + 32 * q] = acc[a][q][r];
+        } else {
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+#pragma unroll
+                for (int q = 0; q < QB; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dn = a * 32 + gmt_acc_row(r, lane);
+                        if (n0 + dn < N && i0 + 32 * q < I) out[(long long)dn * I + 32 * q] = acc[a][q][r];
+                    }
+        }
+    }
     // bias gradient: column sums of this slab of dA (only the it == 0 workgroups write)
     if (db_slab && it == 0) {
         __syncthreads();
-        float* red = &sA[0][0][0];                      // reuse: [4][256]
-        red[a_r0 * WG_TN + 4 * a_c4 + 0] = colsum.x; red[a_r0 * WG_TN + 4 * a_c4 + 1] = colsum.y;
-        red[a_r0 * WG_TN + 4 * a_c4 + 2] = colsum.z; red[a_r0 * WG_TN + 4 * a_c4 + 3] = colsum.w;
+        float* red = &sA[0][0][0];                      // reuse: [ARG][TN]
+        red[a_r0 * TN + 4 * a_c4 + 0] = colsum.x; red[a_r0 * TN + 4 * a_c4 + 1] = colsum.y;
+        red[a_r0 * TN + 4 * a_c4 + 2] = colsum.z; red[a_r0 * TN + 4 * a_c4 + 3] = colsum.w;
         __syncthreads();
-        const float v = red[tid] + red[WG_TN + tid] + red[2 * WG_TN + tid] + red[3 * WG_TN + tid];
-        db_slab[(long long)ks * N + (long long)nt * WG_TN + tid] = v;
+        if (tid < TN && nt * TN + tid < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < ARG; ++g) v += red[g * TN + tid];
+            db_slab[(long long)ks * N + (long long)nt * TN + tid] = v;
+        }
     }
 }
 
@@ -127,12 +207,35 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
     }
 }
 
+// the same one float at a time (N * I not a multiple of 4, e.g. I = 9)
+__global__ void slab_reduce_scalar_kernel(const float* __restrict__ slab, float* __restrict__ out, long long n, int ksplit,
+                                          int accumulate)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = accumulate ? out[i] : 0.f;
+        for (int k = 0; k < ksplit; ++k) s += slab[(long long)k * n + i];
+        out[i] = s;
+    }
+}
+
 }  // namespace
+
+// tile shape for (N, I): 0 = <2,4>, 1 = <1,4>, 2 = <2,1>, 3 = <1,1>; -1 unsupported
+static int wgrad_shape(int N, int I, long long ldx)
+{
+    if (N < 4 || (N % 4) != 0 || I < 1) return -1;
+    const bool wide = (I % 128) == 0 && (ldx % 4) == 0;
+    if (!wide && I > 32) return -1;
+    const bool big = (N % 256) == 0;
+    return wide ? (big ? 0 : 1) : (big ? 2 : 3);
+}
 
 extern "C" int gmt_wgrad_workspace_floats(int N, int I, long long R, int* ksplit_out, long long* floats_out)
 {
-    GMT_CHECK_ARG(N >= WG_TN && (N % WG_TN) == 0 && I >= WG_TI && (I % WG_TI) == 0 && R >= WG_RC && (R % WG_RC) == 0);
-    const int tiles = (N / WG_TN) * (I / WG_TI);
+    const int shape = wgrad_shape(N, I, 4);
+    GMT_CHECK_ARG(shape >= 0 && R >= WG_RC && (R % WG_RC) == 0);
+    const int TN = (shape == 0 || shape == 2) ? 256 : 128, TI = (shape <= 1) ? 128 : 32;
+    const int tiles = ((N + TN - 1) / TN) * ((I + TI - 1) / TI);
     int ks = (2 * 256 + tiles - 1) / tiles;             // ~2 workgroups per CU
     const long long n_chunks = R / WG_RC;
     if (ks > n_chunks) ks = (int)n_chunks;
@@ -147,18 +250,31 @@ extern "C" int gmt_wgrad(const float* dA, long long lda, const float* X, long lo
                          hipStream_t stream)
 {
     GMT_CHECK_ARG(dA && X && dW && workspace);
-    GMT_CHECK_ARG((lda % 4) == 0 && (ldx % 4) == 0 && (((uintptr_t)dA | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) & 15) == 0);
+    const int shape = wgrad_shape(N, I, ldx);
+    GMT_CHECK_ARG(shape >= 0);
+    GMT_CHECK_ARG((lda % 4) == 0 && (((uintptr_t)dA | (uintptr_t)workspace) & 15) == 0);
+    if (shape <= 1) GMT_CHECK_ARG(((uintptr_t)X & 15) == 0);
     int ks = 0; long long need = 0;
     const int rc = gmt_wgrad_workspace_floats(N, I, R, &ks, &need);
     if (rc != GMT_OK) return rc;
     if (workspace_floats < need) return GMT_ERR_WORKSPACE;
     float* slab = workspace;
     float* db_slab = db ? workspace + (long long)ks * N * I : nullptr;
-    const int grid = ks * (N / WG_TN) * (I / WG_TI);
-    hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks);
+    const int TN = (shape == 0 || shape == 2) ? 256 : 128, TI = (shape <= 1) ? 128 : 32;
+    const int tiles = ((N + TN - 1) / TN) * ((I + TI - 1) / TI);
+    const int grid = 8 * tiles * ((ks + 7) / 8);
+    switch (shape) {
+    case 0: hipLaunchKernelGGL((wgrad_kernel<2, 4>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks); break;
+    case 1: hipLaunchKernelGGL((wgrad_kernel<1, 4>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks); break;
+    case 2: hipLaunchKernelGGL((wgrad_kernel<2, 1>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks); break;
+    default: hipLaunchKernelGGL((wgrad_kernel<1, 1>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks); break;
+    }
     GMT_LAUNCH_CHECK();
     const long long n = (long long)N * I;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(gmt_grid_1d(n / 4, 256)), dim3(256), 0, stream, slab, dW, n, ks, accumulate);
+    if ((n % 4) == 0 && (((uintptr_t)dW) & 15) == 0)
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gmt_grid_1d(n / 4, 256)), dim3(256), 0, stream, slab, dW, n, ks, accumulate);
+    else
+        hipLaunchKernelGGL(slab_reduce_scalar_kernel, dim3(gmt_grid_1d(n, 256)), dim3(256), 0, stream, slab, dW, n, ks, accumulate);
     GMT_LAUNCH_CHECK();
     if (db) {
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(gmt_grid_1d(N / 4, 256)), dim3(256), 0, stream, db_slab, db,

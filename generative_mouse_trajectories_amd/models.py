@@ -74,6 +74,8 @@ class SNLinear(nn.Module):
         return w / sigma
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda and x.dim() == 3:          # per-timestep use: weight gradient over L*B rows on the split-K kernel
+            return ops.linear(x, self.compute_weight(), self.bias)
         return F.linear(x, self.compute_weight(), self.bias)
 
 

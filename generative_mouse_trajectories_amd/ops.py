@@ -11,6 +11,7 @@ from __future__ import annotations
 from typing import List, Optional, Tuple
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib as L_
 
@@ -90,11 +91,14 @@ def pack_transposed(ws: List[torch.Tensor], n_out: int, K: int, col0: int = 0, n
 # ----------------------------------------------------------------------------------------
 def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False):
     """dW = dA^T X over the rows (dA [R,N] contiguous, X [R,I] a row-strided view); optionally
-    db = dA.sum(0).  Shapes outside the kernel's tiling (N % 256, I % 128, R % 32) go to rocBLAS."""
+    db = dA.sum(0).  Kernel shapes (csrc/wgrad.hip): N % 4 == 0 and either I % 128 == 0 with a
+    16-byte aligned X, or a skinny X (I <= 32, any row pitch); R % 16 == 0.  Anything else goes
+    to rocBLAS."""
     R, N = dA.shape
     I = X.shape[1]
-    ok = (N % 256 == 0 and I % 128 == 0 and R % 32 == 0 and R >= 32 and dA.is_contiguous()
-          and X.stride(1) == 1 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and dA.data_ptr() % 16 == 0)
+    wide = I % 128 == 0 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
+    ok = (dA.is_cuda and N % 4 == 0 and R % 16 == 0 and R >= 16 and dA.is_contiguous() and dA.data_ptr() % 16 == 0
+          and X.stride(1) == 1 and (wide or I <= 32) and dA.dtype == torch.float32 and X.dtype == torch.float32)
     if not ok:
         dW = torch.mm(dA.t(), X)
         return dW, (dA.sum(0) if want_db else None)
@@ -105,8 +109,37 @@ def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False):
     dW = torch.empty(N, I, device=dA.device, dtype=torch.float32)
     db = torch.empty(N, device=dA.device, dtype=torch.float32) if want_db else None
     L_.call('gmt_wgrad', dA.data_ptr(), N, X.data_ptr(), X.stride(0), R, N, I, dW.data_ptr(),
-            None if db is None else db.data_ptr(), 0, ws.data_ptr(), need.value, L_.stream(), label=f'wgrad_I{I}')
+            None if db is None else db.data_ptr(), 0, ws.data_ptr(), need.value, L_.stream(), label=f'wgrad_N{N}_I{I}')
     return dW, db
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b over the rows of x [..., I] (the per-timestep Linear layers of the feature
+    encoder, RG.py:713-718, applied to L*B rows).  Forward and dx are library GEMMs; the weight and
+    bias gradients - a [N x R] x [R x I] contraction with R ~ 5e5 - run on the split-K kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        x2 = x.reshape(-1, x.shape[-1])
+        dx = (dy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            dW, db = wgrad(dy2, x2, want_db=ctx.has_b)
+        return dx, dW, db
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    return LinearFn.apply(x, w, b)
 
 
 # ----------------------------------------------------------------------------------------
@@ -440,13 +473,12 @@ class GenRolloutFn(torch.autograd.Function):
         da1 = gates1.view(T * B, 4 * H)
         h0v, h1v = h0.view(T * B, H), h1.view(T * B, H)
         d_g0 = gates0.sum(0)                                            # time-invariant input: sum over t
-        d_w_u = torch.mm(da0.t(), u.view(T * B, 8))[:, :7]
+        d_w_u = wgrad(da0, u.view(T * B, 8))[0][:, :7]
         d_w_hh0 = wgrad(da0[B:], h0v[:-B])[0] if T > 1 else torch.zeros_like(w_hh0)
         d_w_ih1, d_bias1 = wgrad(da1, h0d.view(T * B, H), want_db=True)
         d_w_hh1 = wgrad(da1[B:], h1v[:-B])[0] if T > 1 else torch.zeros_like(w_hh1)
         dyp = d_ypre.view(T * B, HH)
-        d_w1 = torch.mm(dyp.t(), h1v)
-        d_b1 = dyp.sum(0)
+        d_w1, d_b1 = wgrad(dyp, h1v, want_db=True)
         dov = d_o.view(T * B, 3)
         d_w2 = torch.mm(dov.t(), y.view(T * B, HH))
         d_b2 = dov.sum(0)

@@ -157,7 +157,12 @@ def test_telemetry_kernel_bit_exact():
 
 
 @pytest.mark.parametrize('R,N,I,ldx,shift', [(32 * 40, 512, 128, 256, 0), (32 * 129, 512, 256, 256, 32),
-                                            (32 * 700, 512, 128, 128, 0), (64, 256, 128, 128, 0)])
+                                            (32 * 700, 512, 128, 128, 0), (64, 256, 128, 128, 0),
+                                            # the other tilings: N = 128 / 64 (zero-padded tile), skinny X (I <= 32,
+                                            # odd row pitch), odd chunk counts, a slab per chunk
+                                            (16 * 37, 128, 128, 128, 0), (32 * 100, 64, 128, 128, 0),
+                                            (32 * 300, 128, 9, 9, 0), (32 * 129, 512, 8, 8, 32),
+                                            (16 * 3, 384, 128, 128, 0), (16, 512, 256, 256, 0), (32 * 50, 36, 7, 11, 0)])
 def test_wgrad_kernel(ops, R, N, I, ldx, shift):
     torch.manual_seed(R + I)
     dA = torch.randn(R + shift, N, device=DEV)
@@ -170,3 +175,25 @@ def test_wgrad_kernel(ops, R, N, I, ldx, shift):
     H.assert_close(db, a.double().sum(0), 2e-6, 'db')
     dW2, _ = ops.wgrad(a, x)
     assert torch.equal(dW, dW2), 'the slab reduction must be deterministic'
+
+
+def test_linear_fn_matches_autograd(ops):
+    torch.manual_seed(5)
+    x = torch.randn(12, 64, 9, device=DEV, requires_grad=True)
+    w = torch.randn(128, 9, device=DEV, requires_grad=True)
+    b = torch.randn(128, device=DEV, requires_grad=True)
+    g = torch.randn(12, 64, 128, device=DEV)
+    y = ops.linear(x, w, b)
+    dx, dw, db = torch.autograd.grad(y, (x, w, b), g)
+    yr = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    rx, rw, rb = torch.autograd.grad(yr, (x, w, b), g.double())
+    H.assert_close(y, yr.detach(), 1e-6, 'y')
+    H.assert_close(dx, rx, 1e-6, 'dx'); H.assert_close(dw, rw, 2e-6, 'dw'); H.assert_close(db, rb, 2e-6, 'db')
+    # double backward (gradient-penalty use): d/dw of |dL/dx|^2
+    y = ops.linear(x, w, b)
+    gx, = torch.autograd.grad(y, x, g, create_graph=True)
+    (gx ** 2).sum().backward()
+    x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    gx64, = torch.autograd.grad(torch.nn.functional.linear(x64, w64, b.double()), x64, g.double(), create_graph=True)
+    (gx64 ** 2).sum().backward()
+    H.assert_close(w.grad, w64.grad, 1e-5, 'd2w')
