@@ -79,8 +79,10 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
     int cur = 0;
     __syncthreads();
 
+    GMT_PH_DECL;
     for (int t = 0; t < T; ++t) {
         const size_t rs = (size_t)t * B + lane_row;
+        GMT_PH(7);
         // ---- S1: dynamic features of the current position (RG.py:486-506) + current input
         if (tid < GMT_TM) {
             const float rx = ex - px, ry = ey - py;
@@ -95,7 +97,9 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
                 up[1] = make_float4(ry, dist, ang, 0.f);
             }
         }
+        GMT_PH(0);
         __syncthreads();
+        GMT_PH(1);
         // ---- S2: layer 0
         {
             f32x16 acc[4];
@@ -133,6 +137,7 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
                 if (sh) sh[(size_t)mr * H] = hv;
             }
         }
+        GMT_PH(2);
         __syncthreads();
         // ---- S3: layer 1
         {
@@ -162,6 +167,7 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
                 if (sh) sh[(size_t)mr * H] = hv;
             }
         }
+        GMT_PH(3);
         __syncthreads();
         // ---- S4: head layer 1, Linear(H -> H/2) + LeakyReLU (RG.py:460-462)
         if (wave < NH) {
@@ -179,7 +185,9 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
                 if (sy) sy[(size_t)mr * HH] = y;
             }
         }
+        GMT_PH(4);
         __syncthreads();
+        GMT_PH(5);
         // ---- S5: Linear(H/2 -> 3), softplus on dt, position / next-input update (RG.py:574-595)
         if (tid < GMT_TM) {
             const float* w2 = gmt_opaque_s(a.w2);
@@ -207,8 +215,10 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
             if (tf) { in0 = t0; in1 = t1; in2 = t2; px = tpx; py = tpy; }
             else { in0 = o0; in1 = o1; in2 = dt; }
         }
+        GMT_PH(6);
         cur ^= 1;
     }
+    GMT_PH_DUMP;
 }
 
 // ---------------------------------------------------------------------------- backward
@@ -225,16 +235,22 @@ __device__ __forceinline__ void cell_bwd(float dht, float& dc, float ig, float f
     dc = dct * fg;
 }
 
+// Every operand of step t-1 is requested while step t's contractions run (one accumulator row of
+// loads ahead of a group of MFMAs): layer 0's saved gates under B4, layer 1's and the per-row
+// scalars under B6.  c_t is carried from the c_{t-1} fetch of the step before.
 template <int NW, bool RES0>
 __global__ __launch_bounds__(NW * 64, 1)
 void gen_bwd_kernel(gmt_gen_bwd_args a)
 {
     constexpr int H = NW * 32, HH = H / 2, NT = NW * 64, NP = NT / 32;
     constexpr int KS4 = 2 * H;                         // k-steps over K = 4H
+    constexpr int NY = (GMT_TM * HH) / NT;             // head activations per thread (B2)
     extern __shared__ float smem[];
     float* daT = smem;                                 // [4H][LDA]
     float* dyT = daT + 4 * H * GMT_LDA;                // [HH][LDA]; later aliased by the du partials [NP][8][32]
     float* doS = dyT + HH * GMT_LDA;                   // [3][32]
+    constexpr bool WUL = (NW <= 4);                    // W_u [4H][8] (zero-padded) cached in LDS when it fits: read by every thread in B6
+    float* wuS = doS + 96;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -248,6 +264,9 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
     const float4* whh0T = reinterpret_cast<const float4*>(a.w_hh0T_pk) + (size_t)wave * (4 * H / 8) * 64;
     float wr0[1][RES0 ? KS4 : 1];
     if constexpr (RES0) gmt_load_resident<1, KS4>(wr0, whh0T, lane);
+    if constexpr (WUL) {
+        for (int i = tid; i < 4 * H * 8; i += NT) wuS[i] = a.w_uP[i];
+    }
 
     float dh0[16], dc0[16], dh1[16], dc1[16];
 #pragma unroll
@@ -258,34 +277,86 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
     const float keep_scale = 1.0f / (1.0f - a.dropout_p);
     const size_t lane_row = (size_t)row0 + 4 * hi;
 
+    // prefetch registers
+    float g1[4][16], cp1[16], cn1[16];                 // layer 1: gates of step t, c_{t-1}, c_t
+    float g0[4][16], cp0[16], cn0[16];                 // layer 0
+    float py[NY];                                      // y_all of step t (B2 map: row tid/HH + (NT/HH) j, unit tid%HH)
+    float pdo0 = 0.f, pdo1 = 0.f, pdo2 = 0.f, po2 = 0.f, prx = 0.f, pry = 0.f, pdist = 1.f;   // threads 0..31
+    static_assert(NT % HH == 0, "B2 thread map");
+    auto fetch_row1 = [&](int t, int r) {
+        const int mr = (r & 3) + 8 * (r >> 2);
+        const float* q = a.gates1 + (((size_t)t * B + lane_row) + mr) * (4 * H) + col;
+        g1[0][r] = q[0]; g1[1][r] = q[H]; g1[2][r] = q[2 * H]; g1[3][r] = q[3 * H];
+        const int tp = t > 0 ? t - 1 : 0;              // (t = 0: c_{-1} = 0 is selected at use)
+        cp1[r] = a.c1_all[(((size_t)tp * B + lane_row) + mr) * H + col];
+    };
+    auto fetch_row0 = [&](int t, int r) {
+        const int mr = (r & 3) + 8 * (r >> 2);
+        const float* q = a.gates0 + (((size_t)t * B + lane_row) + mr) * (4 * H) + col;
+        g0[0][r] = q[0]; g0[1][r] = q[H]; g0[2][r] = q[2 * H]; g0[3][r] = q[3 * H];
+        const int tp = t > 0 ? t - 1 : 0;
+        cp0[r] = a.c0_all[(((size_t)tp * B + lane_row) + mr) * H + col];
+    };
+    auto fetch_small = [&](int t) {
+        const size_t yb = ((size_t)t * B + row0 + tid / HH) * HH + tid % HH;
+#pragma unroll
+        for (int j = 0; j < NY; ++j) py[j] = a.y_all[yb + (size_t)j * (NT / HH) * HH];
+        if (tid < GMT_TM) {
+            const size_t rr = (size_t)t * B + row0 + tid;
+            pdo0 = a.d_out[rr * 3]; pdo1 = a.d_out[rr * 3 + 1]; pdo2 = a.d_out[rr * 3 + 2];
+            po2 = a.oraw_all[rr];
+            prx = a.u_all[rr * 8 + 3]; pry = a.u_all[rr * 8 + 4]; pdist = a.u_all[rr * 8 + 5];
+        }
+    };
+    {
+        const int t = T - 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            fetch_row1(t, r);
+            const int mr = (r & 3) + 8 * (r >> 2);
+            cn1[r] = a.c1_all[(((size_t)t * B + lane_row) + mr) * H + col];
+            cn0[r] = a.c0_all[(((size_t)t * B + lane_row) + mr) * H + col];
+        }
+        fetch_small(t);
+    }
+    __syncthreads();
+
+    GMT_PH_DECL;
     for (int t = T - 1; t >= 0; --t) {
         const size_t rs = (size_t)t * B + lane_row;
+        const int tn = t > 0 ? t - 1 : 0;
+        GMT_PH(7);              // the step fetched next (clamped: no branch around loads)
         const bool tf = a.tf_mask && a.tf_mask[t];     // input of step t+1 came from the target
         // ---- B1: gradient of out_t = external + feedback through next input / position
         if (tid < GMT_TM) {
             const size_t ro = ((size_t)t * B + row0 + tid) * 3;
-            float g0 = a.d_out[ro], g1 = a.d_out[ro + 1], g2 = a.d_out[ro + 2];
-            if (!tf) { g0 += din0 + dpx; g1 += din1 + dpy; g2 += din2; }
+            float q0 = pdo0, q1 = pdo1, q2 = pdo2;
+            if (!tf) { q0 += din0 + dpx; q1 += din1 + dpy; q2 += din2; }
             else { dpx = 0.f; dpy = 0.f; }             // pos_{t+1} was reset from the targets: path cut
-            const float o2 = a.oraw_all[(size_t)t * B + row0 + tid];
-            const float sg = o2 > 20.f ? 1.f : 1.f / (1.f + expf(-o2));     // d softplus
-            g2 *= sg;
-            doS[0 * 32 + tid] = g0; doS[1 * 32 + tid] = g1; doS[2 * 32 + tid] = g2;
-            a.d_o[ro] = g0; a.d_o[ro + 1] = g1; a.d_o[ro + 2] = g2;
+            const float sg = po2 > 20.f ? 1.f : 1.f / (1.f + expf(-po2));     // d softplus
+            q2 *= sg;
+            doS[0 * 32 + tid] = q0; doS[1 * 32 + tid] = q1; doS[2 * 32 + tid] = q2;
+            a.d_o[ro] = q0; a.d_o[ro + 1] = q1; a.d_o[ro + 2] = q2;
         }
         __syncthreads();
+        GMT_PH(0);
         // ---- B2: head backward, d(ypre) = (d_o W2) * lrelu'
-        const float* w2 = gmt_opaque_s(a.w2);
-        for (int idx = tid; idx < GMT_TM * HH; idx += NT) {
-            const int k = idx % HH, row = idx / HH;
-            const size_t go = ((size_t)t * B + row0 + row) * HH + k;
-            const float y = a.y_all[go];
-            float v = doS[row] * w2[k] + doS[32 + row] * w2[HH + k] + doS[64 + row] * w2[2 * HH + k];
-            v *= (y > 0.f) ? 1.f : 0.2f;
-            dyT[k * GMT_LDA + row] = v;
-            a.d_ypre[go] = v;
+        {
+            const float* w2 = gmt_opaque_s(a.w2);
+            const int k = tid % HH;
+            const float w20 = w2[k], w21 = w2[HH + k], w22 = w2[2 * HH + k];
+            const size_t yb = ((size_t)t * B + row0 + tid / HH) * HH + k;
+#pragma unroll
+            for (int j = 0; j < NY; ++j) {
+                const int row = tid / HH + j * (NT / HH);
+                float v = doS[row] * w20 + doS[32 + row] * w21 + doS[64 + row] * w22;
+                v *= (py[j] > 0.f) ? 1.f : 0.2f;
+                dyT[k * GMT_LDA + row] = v;
+                a.d_ypre[yb + (size_t)j * (NT / HH) * HH] = v;
+            }
         }
         __syncthreads();
+        GMT_PH(1);
         // ---- B3: dh1 += d(ypre) W1 ; layer-1 cell backward -> da1
         {
             f32x16 acc[1];
@@ -293,25 +364,29 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
             for (int r = 0; r < 16; ++r) acc[0][r] = dh1[r];
             gmt_mma_stream<1>(acc, dyT, w1T, HH, lane);
             float* gp = a.gates1 + rs * (4 * H) + col;
-            const float* cn_p = a.c1_all + rs * H + col;
-            const float* cp_p = a.c1_all + ((size_t)(t > 0 ? t - 1 : 0) * B + lane_row) * H + col;
+            float* dl = daT + col * GMT_LDA + 4 * hi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int mr = (r & 3) + 8 * (r >> 2), m = mr + 4 * hi;
+                const int mr = (r & 3) + 8 * (r >> 2);
                 float* q = gp + (size_t)mr * (4 * H);
-                const float cp = t > 0 ? cp_p[(size_t)mr * H] : 0.f;
+                const float cp = t > 0 ? cp1[r] : 0.f;
                 float dai, daf, dag, dao;
-                cell_bwd(acc[0][r], dc1[r], q[0], q[H], q[2 * H], q[3 * H], cn_p[(size_t)mr * H], cp, dai, daf, dag, dao);
+                cell_bwd(acc[0][r], dc1[r], g1[0][r], g1[1][r], g1[2][r], g1[3][r], cn1[r], cp, dai, daf, dag, dao);
+                cn1[r] = cp1[r];
                 q[0] = dai; q[H] = daf; q[2 * H] = dag; q[3 * H] = dao;
-                daT[(0 * H + col) * GMT_LDA + m] = dai; daT[(1 * H + col) * GMT_LDA + m] = daf;
-                daT[(2 * H + col) * GMT_LDA + m] = dag; daT[(3 * H + col) * GMT_LDA + m] = dao;
+                dl[0 * H * GMT_LDA + mr] = dai; dl[1 * H * GMT_LDA + mr] = daf;
+                dl[2 * H * GMT_LDA + mr] = dag; dl[3 * H * GMT_LDA + mr] = dao;
             }
         }
         __syncthreads();
-        // ---- B4: dh1_prev = da1 W_hh1 ; dh0_total = dh0 + da1 W_ih1
+        GMT_PH(2);
+        // ---- B4: dh1_prev = da1 W_hh1 ; dh0_total = dh0 + da1 W_ih1   (layer 0's operands of this step arrive)
         f32x16 acc2[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc2[0][r] = 0.f; acc2[1][r] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fetch_row0(t, r);
+        GMT_PH(3);
         gmt_mma_stream<2>(acc2, daT, wl1T, 4 * H, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -324,38 +399,53 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
             acc2[1][r] = dh0[r] + g;
         }
         __syncthreads();
+        GMT_PH(4);
         // ---- B5: layer-0 cell backward -> da0
         {
             float* gp = a.gates0 + rs * (4 * H) + col;
-            const float* cn_p = a.c0_all + rs * H + col;
-            const float* cp_p = a.c0_all + ((size_t)(t > 0 ? t - 1 : 0) * B + lane_row) * H + col;
+            float* dl = daT + col * GMT_LDA + 4 * hi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int mr = (r & 3) + 8 * (r >> 2), m = mr + 4 * hi;
+                const int mr = (r & 3) + 8 * (r >> 2);
                 float* q = gp + (size_t)mr * (4 * H);
-                const float cp = t > 0 ? cp_p[(size_t)mr * H] : 0.f;
+                const float cp = t > 0 ? cp0[r] : 0.f;
                 float dai, daf, dag, dao;
-                cell_bwd(acc2[1][r], dc0[r], q[0], q[H], q[2 * H], q[3 * H], cn_p[(size_t)mr * H], cp, dai, daf, dag, dao);
+                cell_bwd(acc2[1][r], dc0[r], g0[0][r], g0[1][r], g0[2][r], g0[3][r], cn0[r], cp, dai, daf, dag, dao);
+                cn0[r] = cp0[r];
                 q[0] = dai; q[H] = daf; q[2 * H] = dag; q[3 * H] = dao;
-                daT[(0 * H + col) * GMT_LDA + m] = dai; daT[(1 * H + col) * GMT_LDA + m] = daf;
-                daT[(2 * H + col) * GMT_LDA + m] = dag; daT[(3 * H + col) * GMT_LDA + m] = dao;
+                dl[0 * H * GMT_LDA + mr] = dai; dl[1 * H * GMT_LDA + mr] = daf;
+                dl[2 * H * GMT_LDA + mr] = dag; dl[3 * H * GMT_LDA + mr] = dao;
             }
         }
         __syncthreads();
+        GMT_PH(5);
         // ---- B6: dh0_prev = da0 W_hh0 ; partial d(u) = da0 W_u over this thread's 64-wide k slice
+        //          (layer 1's operands and the per-row scalars of step t-1 arrive)
+        float urx = prx, ury = pry, udist = pdist;      // this step's values, before the fetch overwrites them
         {
             f32x16 acc[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-            if constexpr (RES0) gmt_mma_resident<1, KS4>(acc, daT, wr0, lane);
-            else gmt_mma_stream<1>(acc, daT, whh0T, 4 * H, lane);
+            if constexpr (RES0) {
+                gmt_mma_resident<1, KS4>(acc, daT, wr0, lane, nullptr, [&](int grp) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((r * (KS4 / 8)) / 16 == grp) fetch_row1(tn, r);
+                    if (grp == KS4 / 8 - 1) fetch_small(tn);
+                });
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fetch_row1(tn, r);
+                fetch_small(tn);
+                gmt_mma_stream<1>(acc, daT, whh0T, 4 * H, lane);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) dh0[r] = acc[0][r];
             const int part = tid >> 5, row = tid & 31;
             float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const int k0 = part * 64;
-            const float* wup = gmt_opaque_s(a.w_uP);
-#pragma unroll 4
+            const float* wup = WUL ? wuS : gmt_opaque_s(a.w_uP);
+#pragma unroll 8
             for (int k = k0; k < k0 + 64; ++k) {
                 const float d = daT[k * GMT_LDA + row];
                 const float4 wa = reinterpret_cast<const float4*>(wup + (size_t)k * 8)[0];
@@ -369,14 +459,14 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
             for (int j = 0; j < 7; ++j) pp[j * 32] = s[j];
         }
         __syncthreads();
+        GMT_PH(6);
         // ---- B7: reduce d(u); dynamic-feature backward (RG.py:502-506) -> d(pos_t); carry
         if (tid < GMT_TM) {
             float du[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int j = 0; j < 7; ++j) du[j] += dyT[(size_t)p * 8 * 32 + j * 32 + tid];
-            const float* up = a.u_all + ((size_t)t * B + row0 + tid) * 8;
-            const float rx = up[3], ry = up[4], dist = up[5];
+            const float rx = urx, ry = ury, dist = udist;
             const float r2 = rx * rx + ry * ry;
             const float inv = r2 > 0.f ? 1.f / r2 : 0.f;
             const float drx = du[3] + du[5] * rx / dist - du[6] * ry * inv;
@@ -390,6 +480,7 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
             }
         }
     }
+    GMT_PH_DUMP;
 }
 
 template <int NW>
@@ -411,8 +502,8 @@ template <int NW>
 int launch_gen_bwd(const gmt_gen_bwd_args& a, hipStream_t stream)
 {
     constexpr int H = NW * 32, HH = H / 2;
-    constexpr bool RES0 = (NW <= 4);
-    const size_t lds = ((size_t)(4 * H + HH) * GMT_LDA + 96) * sizeof(float);
+    constexpr bool RES0 = (NW <= 2);             // at H >= 128 the prefetch registers need the room: W_hh_l0^T streams from L2
+    const size_t lds = ((size_t)(4 * H + HH) * GMT_LDA + 96 + (NW <= 4 ? 4 * H * 8 : 0)) * sizeof(float);
     if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;
     auto k = gen_bwd_kernel<NW, RES0>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -44,19 +44,6 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
     }
 }
 
-// Phase timing for tuning (scratch/phase_fwd.hip defines GMT_PHASE_TIMING and includes this file);
-// compiled out of the library.
-#ifdef GMT_PHASE_TIMING
-__device__ unsigned long long gmt_phase_ticks[8];
-#define GMT_PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[6] = {0, 0, 0, 0, 0, 0}
-#define GMT_PH(i) do { unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
-#define GMT_PH_DUMP do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) gmt_phase_ticks[i_] = ph_acc[i_]; } while (0)
-#else
-#define GMT_PH_DECL
-#define GMT_PH(i)
-#define GMT_PH_DUMP
-#endif
-
 // ------------------------------------------------------------------ forward
 // NW waves (H = 32 NW).  RES: recurrent weights resident in registers.  IX = I / H:
 //   IX = 0  the caller precomputed x W_ih^T + b into `pregates` (read from HBM);

@@ -86,52 +86,111 @@ __device__ __forceinline__ void gmt_stream_fetch(float4 (&w)[NG], float (&a)[4],
 // the 4*NG MFMAs of group s4 are issued, so an L2 round trip hides under a whole group.  The
 // scheduling fences keep the compiler from sinking the loads back down to their first use
 // (measured on MI355X: 34 -> 29 ns per MFMA, 28.5 being the register-only rate).
-template <int NG>
-__device__ __forceinline__ void gmt_stream_wfetch(float4 (&w)[NG], const float4* __restrict__ wpk, int s4, int lane)
+// One pipeline stage of the streamed contraction = G k-groups (8 k each) = 4*NG*G >= 16 MFMAs:
+// the stage is what one L2 round trip has to hide under.
+template <int NG, int G>
+__device__ __forceinline__ void gmt_stage_fetch(float4 (&w)[G][NG], float (&a)[G][4], const float4* __restrict__ wpk,
+                                                const float* __restrict__ ap, int st, int lane)
 {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) w[g] = wpk[(s4 * NG + g) * 64 + lane];
+    for (int q = 0; q < G; ++q) gmt_stream_fetch<NG>(w[q], a[q], wpk, ap, st * G + q, lane);
 }
 
-// w0 already holds the weights of k-group 0 (gmt_stream_wfetch issued by the caller well before,
-// e.g. ahead of the element-wise phase of the previous step, so the first L2 round trip is hidden too).
-template <int NG>
-__device__ __forceinline__ void gmt_mma_stream_pf(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
-                                                  const float4* __restrict__ wpk, int K, int lane, float4 (&w0)[NG])
+template <int NG, int G>
+__device__ __forceinline__ void gmt_stage_mma(f32x16 (&acc)[NG], f32x16& alt, const float (&a)[G][4], const float4 (&w)[G][NG])
 {
-    const int hi = lane >> 5, lo = lane & 31;
-    const int ns4 = K >> 3;
-    const float* ap = lds_a + hi * GMT_LDA + lo;
-    float4 w1[NG];
-    float a0[4], a1[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a0[j] = ap[2 * j * GMT_LDA];
-    int s4 = 0;
-#pragma unroll 1
-    for (; s4 + 1 < ns4; s4 += 2) {
-        gmt_stream_fetch<NG>(w1, a1, wpk, ap, s4 + 1, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        gmt_mma_group<NG>(acc, a0, w0);
-        __builtin_amdgcn_sched_barrier(0);
-        const int sn = (s4 + 2 < ns4) ? s4 + 2 : ns4 - 1;       // last trip: an in-bounds reload, unused when ns4 is even
-        gmt_stream_fetch<NG>(w0, a0, wpk, ap, sn, lane);        // (unconditional: a branch here makes every wait a full drain)
-        __builtin_amdgcn_sched_barrier(0);
-        gmt_mma_group<NG>(acc, a1, w1);
+    for (int q = 0; q < G; ++q) {
+        if constexpr (NG == 1) {
+            // one-gate form: a second accumulator takes every other k-group, so the chains are half as long
+            if (q & 1) {
+                alt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][0], w[q][0].x, alt, 0, 0, 0);
+                alt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][1], w[q][0].y, alt, 0, 0, 0);
+                alt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][2], w[q][0].z, alt, 0, 0, 0);
+                alt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][3], w[q][0].w, alt, 0, 0, 0);
+                continue;
+            }
+        }
+        gmt_mma_group<NG>(acc, a[q], w[q]);
     }
-    if (ns4 & 1) gmt_mma_group<NG>(acc, a0, w0);
 }
 
-// Two register buffers used in turn (no copies): the operands of k-group s4+1 are requested before
-// the 4*NG MFMAs of group s4 are issued, so an L2 round trip hides under a whole group.  The
-// scheduling fences keep the compiler from sinking the loads back down to their first use
-// (measured on MI355X: 34 -> 29 ns per MFMA, 28.5 being the register-only rate).
+// Two register stages used in turn (no copies): the operands of stage st+1 are requested before
+// the MFMAs of stage st are issued, so an L2 round trip hides under a whole stage.  The scheduling
+// fences keep the compiler from sinking the loads back down to their first use (measured on
+// MI355X: 34 -> 29 ns per MFMA, 28.5 being the register-only rate).  No branch sits between a
+// fetch and its use: a conditional fetch makes every wait a full drain.
 template <int NG>
 __device__ __forceinline__ void gmt_mma_stream(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
                                                const float4* __restrict__ wpk, int K, int lane)
 {
-    float4 w0[NG];
-    gmt_stream_wfetch<NG>(w0, wpk, 0, lane);
-    gmt_mma_stream_pf<NG>(acc, lds_a, wpk, K, lane, w0);
+    constexpr int G = (NG >= 4) ? 1 : (NG == 2 ? 2 : 4);
+    const int hi = lane >> 5, lo = lane & 31;
+    const int ns4 = K >> 3;
+    const int nst = ns4 / G;
+    const float* ap = lds_a + hi * GMT_LDA + lo;
+    f32x16 alt;
+    if constexpr (NG == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) alt[r] = 0.f;
+    }
+    if (nst > 0) {
+        float4 w0[G][NG], w1[G][NG];
+        float a0[G][4], a1[G][4];
+        gmt_stage_fetch<NG, G>(w0, a0, wpk, ap, 0, lane);
+        int st = 0;
+#pragma unroll 1
+        for (; st + 1 < nst; st += 2) {
+            gmt_stage_fetch<NG, G>(w1, a1, wpk, ap, st + 1, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            gmt_stage_mma<NG, G>(acc, alt, a0, w0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int sn = (st + 2 < nst) ? st + 2 : nst - 1;       // last trip: an in-bounds reload, unused when nst is even
+            gmt_stage_fetch<NG, G>(w0, a0, wpk, ap, sn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            gmt_stage_mma<NG, G>(acc, alt, a1, w1);
+        }
+        if (nst & 1) gmt_stage_mma<NG, G>(acc, alt, a0, w0);
+    }
+    if constexpr (G > 1) {
+        for (int s4 = nst * G; s4 < ns4; ++s4) {                    // K not a multiple of 8 G: the odd groups
+            float4 w[NG]; float a[4];
+            gmt_stream_fetch<NG>(w, a, wpk, ap, s4, lane);
+            gmt_mma_group<NG>(acc, a, w);
+        }
+    }
+    if constexpr (NG == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] += alt[r];
+    }
+}
+
+// gmt_mma_stream for a compile-time K, fully unrolled, with the side hook of gmt_mma_resident:
+// side(i) is called K/8 times (i = k-group index), each ahead of 4*NG MFMAs.
+template <int NG, int K, class Side>
+__device__ __forceinline__ void gmt_mma_stream_static(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
+                                                      const float4* __restrict__ wpk, int lane, Side side)
+{
+    constexpr int ns4 = K / 8;
+    static_assert(ns4 % 2 == 0, "K must be a multiple of 16");
+    const int hi = lane >> 5, lo = lane & 31;
+    const float* ap = lds_a + hi * GMT_LDA + lo;
+    float4 w0[NG], w1[NG];
+    float a0[4], a1[4];
+    gmt_stream_fetch<NG>(w0, a0, wpk, ap, 0, lane);
+#pragma unroll
+    for (int s4 = 0; s4 < ns4; s4 += 2) {
+        gmt_stream_fetch<NG>(w1, a1, wpk, ap, s4 + 1, lane);
+        side(s4);
+        __builtin_amdgcn_sched_barrier(0);
+        gmt_mma_group<NG>(acc, a0, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s4 + 2 < ns4) gmt_stream_fetch<NG>(w0, a0, wpk, ap, s4 + 2, lane);   // static after unrolling
+        side(s4 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        gmt_mma_group<NG>(acc, a1, w1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // Same contraction with the weights already on chip: wr[g][s], s = k-step, holds the first KR
@@ -223,3 +282,17 @@ __device__ __forceinline__ void gmt_load_resident(float (&wr)[NG][KS], const flo
             wr[g][4 * s4 + 0] = v.x; wr[g][4 * s4 + 1] = v.y; wr[g][4 * s4 + 2] = v.z; wr[g][4 * s4 + 3] = v.w;
         }
 }
+
+// Phase timing for tuning (the scratch/phase_*.hip drivers define GMT_PHASE_TIMING and include a kernel file);
+// compiled out of the library.
+#ifdef GMT_PHASE_TIMING
+__device__ unsigned long long gmt_phase_ticks[8];
+#define GMT_PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GMT_PH(i) do { unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
+#define GMT_PH_DUMP do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) gmt_phase_ticks[i_] = ph_acc[i_]; } while (0)
+#else
+#define GMT_PH_DECL
+#define GMT_PH(i)
+#define GMT_PH_DUMP
+#endif
+

@@ -1,0 +1,35 @@
+// phase timing of gen_fwd_kernel<4,true> in training mode (tuning aid, not part of the library)
+#define GMT_PHASE_TIMING
+#include "../generative_mouse_trajectories_amd/csrc/gen_rollout.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+static float* dz(size_t n) { float* p; CK(hipMalloc(&p, n * 4)); CK(hipMemset(p, 0, n * 4)); return p; }
+int main()
+{
+    const int T = 128, B = 4096, H = 128, HH = 64;
+    gmt_gen_fwd_args a; memset(&a, 0, sizeof(a));
+    a.g0 = dz((size_t)B * 4 * H); a.w_u_pk = dz(4 * H * 8); a.w_hh0_pk = dz(4 * H * H); a.w_ih1_pk = dz(4 * H * H);
+    a.w_hh1_pk = dz(4 * H * H); a.bias1 = dz(4 * H); a.w1_pk = dz((size_t)H * H); a.b1 = dz(HH); a.w2 = dz(3 * HH); a.b2 = dz(3);
+    a.starts = dz(B * 2); a.ends = dz(B * 2); a.init_in = dz(3); a.out_seq = dz((size_t)T * B * 3);
+    a.gates0 = dz((size_t)T * B * 4 * H); a.c0_all = dz((size_t)T * B * H); a.h0_all = dz((size_t)T * B * H);
+    a.gates1 = dz((size_t)T * B * 4 * H); a.c1_all = dz((size_t)T * B * H); a.h1_all = dz((size_t)T * B * H);
+    a.u_all = dz((size_t)T * B * 8); a.y_all = dz((size_t)T * B * HH); a.oraw_all = dz((size_t)T * B); a.h0d_all = dz((size_t)T * B * H);
+    a.T = T; a.B = B; a.H = H; a.dropout_p = 0.1f; a.seed = 1234;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const char* nm[8] = {"S1 feat", "bar", "S2 layer0", "S3 layer1", "S4 head", "bar", "S5 out", "top"};
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        int rc = gmt_gen_rollout_fwd(&a, 0);
+        CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+        if (rc) { printf("rc %d\n", rc); return 1; }
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long t[8]; CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(gmt_phase_ticks), sizeof(t)));
+        double tot = 0; for (int i = 0; i < 8; ++i) tot += t[i];
+        printf("%.3f ms  ticks/step:", ms);
+        for (int i = 0; i < 8; ++i) printf("  %s %.0f", nm[i], t[i] / (double)T);
+        printf("  total %.0f (%.2f ticks/ns)\n", tot / T, tot / (ms * 1e6));
+    }
+    return 0;
+}
