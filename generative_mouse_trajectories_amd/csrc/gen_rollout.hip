@@ -20,7 +20,9 @@ namespace {
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // F.softplus
 __device__ __forceinline__ float lrelu_f(float x) { return x > 0.f ? x : 0.2f * x; }
 
-template <int NW, bool RES0>
+// TRAIN: every saved-activation buffer is present (the host entry point checks all-or-none): no
+// per-row pointer tests.  Otherwise a no-grad rollout that stores only out_seq.
+template <int NW, bool RES0, bool TRAIN>
 __global__ __launch_bounds__(NW * 64, 1)
 void gen_fwd_kernel(gmt_gen_fwd_args a)
 {
@@ -35,6 +37,12 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
     float* yT = h1T + H1B * H * GMT_LDA;               // [NH*32][LDA]
     float* uT = yT + NH * 32 * GMT_LDA;                // [8][LDA]
     float* h0dT = uT + 8 * GMT_LDA;                    // [H][LDA] layer-0 output after dropout (dropout_p > 0)
+    float* w2S = h0dT + H * GMT_LDA;                   // [3][HH] head weights
+    float* oP = w2S + 3 * HH;                          // [NT/32][3][32] partial head outputs
+    // at H = 128 the last KL k-steps of W_hh_l0 live in LDS, not registers (the serial tail spills otherwise)
+    constexpr int KL = (RES0 && NW == 4) ? 16 : 0;
+    constexpr int KR = KS - KL;
+    float4* wl = reinterpret_cast<float4*>(oP + (NT / 32) * 96) + (size_t)(threadIdx.x >> 6) * (KL / 4) * 4 * 64;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -49,10 +57,14 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
     const float4* whh1 = reinterpret_cast<const float4*>(a.w_hh1_pk) + (size_t)wave * (H / 8) * 4 * 64;
     const float4* w1 = reinterpret_cast<const float4*>(a.w1_pk) + (size_t)wave * (H / 8) * 64;
 
-    float wr0[4][RES0 ? KS : 1];
-    if constexpr (RES0) gmt_load_resident<4, KS>(wr0, whh0, lane);
+    float wr0[4][RES0 ? KR : 1];
+    if constexpr (RES0) {
+        gmt_load_resident<4, KR>(wr0, whh0, lane);
+        for (int i = lane; i < (KL / 4) * 4 * 64; i += 64) wl[i] = whh0[(KR / 4) * 4 * 64 + i];   // visible after the first barrier
+    }
 
     for (int i = tid; i < (2 + H1B) * H * GMT_LDA + NH * 32 * GMT_LDA + 8 * GMT_LDA; i += NT) smem[i] = 0.f;
+    for (int i = tid; i < 3 * HH; i += NT) w2S[i] = a.w2[i];
     const bool drop = a.dropout_p > 0.f;
     const uint32_t thresh24 = (uint32_t)(a.dropout_p * 16777216.0f);
     const float keep_scale = 1.0f / (1.0f - a.dropout_p);
@@ -77,6 +89,15 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
     }
     const size_t lane_row = (size_t)row0 + 4 * hi;
     int cur = 0;
+    f32x16 acc0[4];
+    auto g0_load = [&]() {
+        const float* gp = gmt_opaque_v(a.g0 + lane_row * (4 * H) + col);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[g][r] = gp[(size_t)((r & 3) + 8 * (r >> 2)) * (4 * H) + g * H];
+    };
+    g0_load();
     __syncthreads();
 
     GMT_PH_DECL;
@@ -91,7 +112,7 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
             uT[0 * GMT_LDA + tid] = in0; uT[1 * GMT_LDA + tid] = in1; uT[2 * GMT_LDA + tid] = in2;
             uT[3 * GMT_LDA + tid] = rx; uT[4 * GMT_LDA + tid] = ry; uT[5 * GMT_LDA + tid] = dist;
             uT[6 * GMT_LDA + tid] = ang; uT[7 * GMT_LDA + tid] = 0.f;
-            if (a.u_all) {
+            if (TRAIN) {
                 float4* up = reinterpret_cast<float4*>(a.u_all + ((size_t)t * B + row0 + tid) * 8);
                 up[0] = make_float4(in0, in1, in2, rx);
                 up[1] = make_float4(ry, dist, ang, 0.f);
@@ -100,22 +121,17 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
         GMT_PH(0);
         __syncthreads();
         GMT_PH(1);
-        // ---- S2: layer 0
+        // ---- S2: layer 0   (acc0 = the time-invariant g0 tile, requested during the previous step's serial tail)
         {
-            f32x16 acc[4];
-            const float* gp = gmt_opaque_v(a.g0 + lane_row * (4 * H) + col);
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[g][r] = gp[(size_t)((r & 3) + 8 * (r >> 2)) * (4 * H) + g * H];
+            f32x16 (&acc)[4] = acc0;
             gmt_mma_stream<4>(acc, uT, wu, 8, lane);
-            if constexpr (RES0) gmt_mma_resident<4, KS>(acc, h0T + (size_t)cur * H * GMT_LDA, wr0, lane);
+            if constexpr (RES0) gmt_mma_resident<4, KS, KR>(acc, h0T + (size_t)cur * H * GMT_LDA, wr0, lane, wl);
             else gmt_mma_stream<4>(acc, h0T + (size_t)cur * H * GMT_LDA, whh0, H, lane);
             float* hn = h0T + (size_t)(cur ^ 1) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
-            float* sg = a.gates0 ? a.gates0 + rs * (4 * H) + col : nullptr;
-            float* sc = a.c0_all ? a.c0_all + rs * H + col : nullptr;
-            float* sh = a.h0_all ? a.h0_all + rs * H + col : nullptr;
-            float* shd = (a.h0d_all && drop) ? a.h0d_all + rs * H + col : nullptr;
+            float* sg = TRAIN ? a.gates0 + rs * (4 * H) + col : nullptr;
+            float* sc = TRAIN ? a.c0_all + rs * H + col : nullptr;
+            float* sh = TRAIN ? a.h0_all + rs * H + col : nullptr;
+            float* shd = TRAIN ? a.h0d_all + rs * H + col : nullptr;
             float* hd = h0dT + col * GMT_LDA + 4 * hi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -130,11 +146,13 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
                     const uint32_t idx = (uint32_t)((rs + mr) * H + col);
                     const float hdv = gmt_keep(idx, a.seed, thresh24) ? hv * keep_scale : 0.f;
                     hd[mr] = hdv;
-                    if (shd) shd[(size_t)mr * H] = hdv;
+                    if (TRAIN) shd[(size_t)mr * H] = hdv;
                 }
-                if (sg) { float* q = sg + (size_t)mr * (4 * H); q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og; }
-                if (sc) sc[(size_t)mr * H] = cn;
-                if (sh) sh[(size_t)mr * H] = hv;
+                if (TRAIN) {
+                    float* q = sg + (size_t)mr * (4 * H); q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og;
+                    sc[(size_t)mr * H] = cn;
+                    sh[(size_t)mr * H] = hv;
+                }
             }
         }
         GMT_PH(2);
@@ -150,9 +168,9 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
             gmt_mma_stream<4>(acc, h1T + (size_t)(H1S ? 0 : cur) * H * GMT_LDA, whh1, H, lane);
             if constexpr (H1S) __syncthreads();
             float* hn = h1T + (size_t)(H1S ? 0 : (cur ^ 1)) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
-            float* sg = a.gates1 ? a.gates1 + rs * (4 * H) + col : nullptr;
-            float* sc = a.c1_all ? a.c1_all + rs * H + col : nullptr;
-            float* sh = a.h1_all ? a.h1_all + rs * H + col : nullptr;
+            float* sg = TRAIN ? a.gates1 + rs * (4 * H) + col : nullptr;
+            float* sc = TRAIN ? a.c1_all + rs * H + col : nullptr;
+            float* sh = TRAIN ? a.h1_all + rs * H + col : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mr = (r & 3) + 8 * (r >> 2);
@@ -162,9 +180,11 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
                 const float hv = og * gmt_tanh(cn);
                 c1[r] = cn;
                 hn[mr] = hv;
-                if (sg) { float* q = sg + (size_t)mr * (4 * H); q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og; }
-                if (sc) sc[(size_t)mr * H] = cn;
-                if (sh) sh[(size_t)mr * H] = hv;
+                if (TRAIN) {
+                    float* q = sg + (size_t)mr * (4 * H); q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og;
+                    sc[(size_t)mr * H] = cn;
+                    sh[(size_t)mr * H] = hv;
+                }
             }
         }
         GMT_PH(3);
@@ -176,7 +196,7 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
             for (int r = 0; r < 16; ++r) acc[0][r] = b1v;
             gmt_mma_stream<1>(acc, h1T + (size_t)(H1S ? 0 : (cur ^ 1)) * H * GMT_LDA, w1, H, lane);
             float* yp = yT + col * GMT_LDA + 4 * hi;
-            float* sy = (a.y_all && col < HH) ? a.y_all + rs * HH + col : nullptr;
+            float* sy = (TRAIN && col < HH) ? a.y_all + rs * HH + col : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mr = (r & 3) + 8 * (r >> 2);
@@ -188,22 +208,36 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
         GMT_PH(4);
         __syncthreads();
         GMT_PH(5);
-        // ---- S5: Linear(H/2 -> 3), softplus on dt, position / next-input update (RG.py:574-595)
+        // ---- S5: Linear(H/2 -> 3): every thread sums a slice of k for one row, threads 0..31 finish;
+        //          softplus on dt, position / next-input update (RG.py:574-595)
+        g0_load();                                     // next step's layer-0 accumulator init, in flight under the serial tail
+        {
+            constexpr int NP = NT / 32, KP = (HH + NP - 1) / NP;
+            const int part = tid >> 5, row = tid & 31;
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const int k = part * KP + j;
+                if (k < HH) {
+                    const float y = yT[k * GMT_LDA + row];
+                    p0 = fmaf(y, w2S[k], p0); p1 = fmaf(y, w2S[HH + k], p1); p2 = fmaf(y, w2S[2 * HH + k], p2);
+                }
+            }
+            oP[(part * 3 + 0) * 32 + row] = p0; oP[(part * 3 + 1) * 32 + row] = p1; oP[(part * 3 + 2) * 32 + row] = p2;
+        }
+        __syncthreads();
         if (tid < GMT_TM) {
-            const float* w2 = gmt_opaque_s(a.w2);
+            constexpr int NP = NT / 32;
             const float* b2 = gmt_opaque_s(a.b2);
             float o0 = b2[0], o1 = b2[1], o2 = b2[2];
-#pragma unroll 8
-            for (int k = 0; k < HH; ++k) {
-                const float y = yT[k * GMT_LDA + tid];
-                o0 = fmaf(y, w2[k], o0);
-                o1 = fmaf(y, w2[HH + k], o1);
-                o2 = fmaf(y, w2[2 * HH + k], o2);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                o0 += oP[(p * 3 + 0) * 32 + tid]; o1 += oP[(p * 3 + 1) * 32 + tid]; o2 += oP[(p * 3 + 2) * 32 + tid];
             }
             const float dt = softplus_f(o2) + 0.001f;
             const size_t ro = ((size_t)t * B + row0 + tid) * 3;
             a.out_seq[ro] = o0; a.out_seq[ro + 1] = o1; a.out_seq[ro + 2] = dt;
-            if (a.oraw_all) a.oraw_all[(size_t)t * B + row0 + tid] = o2;
+            if (TRAIN) a.oraw_all[(size_t)t * B + row0 + tid] = o2;
             px += o0; py += o1;                                          // RG.py:585
             bool tf = false;
             float t0 = 0.f, t1 = 0.f, t2 = 0.f;
@@ -488,9 +522,10 @@ int launch_gen_fwd(const gmt_gen_fwd_args& a, hipStream_t stream)
 {
     constexpr int H = NW * 32, HH = H / 2, NH = (HH + 31) / 32;
     constexpr bool RES0 = (NW <= 4);
-    const size_t lds = (size_t)((NW > 4 ? 3 : 4) * H + NH * 32 + 8 + H) * GMT_LDA * sizeof(float);
+    const size_t lds = ((size_t)((NW > 4 ? 3 : 4) * H + NH * 32 + 8 + H) * GMT_LDA + 3 * HH + NW * 2 * 96
+                        + ((RES0 && NW == 4) ? NW * 16 * 4 * 64 : 0)) * sizeof(float);
     if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;
-    auto k = gen_fwd_kernel<NW, RES0>;
+    auto k = a.gates0 ? gen_fwd_kernel<NW, RES0, true> : gen_fwd_kernel<NW, RES0, false>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GMT_ERR_HIP;
     hipLaunchKernelGGL(k, dim3(a.B / GMT_TM), dim3(NW * 64), lds, stream, a);
@@ -520,6 +555,12 @@ extern "C" int gmt_gen_rollout_fwd(const gmt_gen_fwd_args* a, hipStream_t stream
     GMT_CHECK_ARG(a && a->g0 && a->w_u_pk && a->w_hh0_pk && a->w_ih1_pk && a->w_hh1_pk && a->bias1 && a->w1_pk &&
                   a->b1 && a->w2 && a->b2 && a->starts && a->ends && a->init_in && a->out_seq);
     GMT_CHECK_ARG(a->T >= 1 && a->B >= GMT_TM && (a->B % GMT_TM) == 0);
+    {   // the saved-activation buffers come all together (training) or not at all (no-grad rollout)
+        const int n_saved = !!a->gates0 + !!a->c0_all + !!a->h0_all + !!a->gates1 + !!a->c1_all + !!a->h1_all + !!a->u_all +
+                            !!a->y_all + !!a->oraw_all;
+        GMT_CHECK_ARG(n_saved == 0 || n_saved == 9);
+        GMT_CHECK_ARG(!(n_saved == 9 && a->dropout_p > 0.f) || a->h0d_all);
+    }
     switch (a->H) {
         case 32: return launch_gen_fwd<1>(*a, stream);
         case 64: return launch_gen_fwd<2>(*a, stream);

@@ -163,7 +163,7 @@ typedef struct gmt_gen_fwd_args {
     const float* target;    /* [T][B][3] or NULL */
     const unsigned char* tf_mask; /* [T] (device) or NULL: 1 = step t+1 is fed the target of step t */
     float* out_seq;         /* [T][B][3] (dx, dy, dt) */
-    /* saved for the backward sweep; all NULL for a no-grad rollout */
+    /* saved for the backward sweep: all nine given (training) or all NULL (no-grad rollout) */
     float* gates0; float* c0_all; float* h0_all;   /* [T][B][4H], [T][B][H], [T][B][H] */
     float* gates1; float* c1_all; float* h1_all;
     float* u_all;           /* [T][B][8]  (in0,in1,in2, rem_x, rem_y, dist, angle, 0) */
