@@ -192,18 +192,35 @@ void wgrad_kernel(const float* __restrict__ dA, long long lda, const float* __re
     }
 }
 
-// out[j] (+)= sum_k slab[k][j]   (fixed order); float4 lanes
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long long n, int ksplit,
-                                   int accumulate)
+// out[j] (+)= sum_k slab[k][j]; float4 lanes.  A block is 64 columns x 4 slab groups: group y sums
+// slabs [y*ksplit/4, (y+1)*ksplit/4) in order, then the four partial sums are added in order, so the
+// result is one fixed association of the additions (deterministic) with 4x the loads in flight.
+__global__ __launch_bounds__(256)
+void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long long n, int ksplit,
+                        int accumulate)
 {
+    __shared__ float4 part[4][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     const long long n4 = n >> 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        float4 s = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < ksplit; ++k) {
-            const float4 v = reinterpret_cast<const float4*>(slab + (long long)k * n)[i];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    const int k0 = (int)((long long)ksplit * y / 4), k1 = (int)((long long)ksplit * (y + 1) / 4);
+    for (long long base = (long long)blockIdx.x * 64; base < n4; base += (long long)gridDim.x * 64) {
+        const long long i = base + x;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4) {
+            for (int k = k0; k < k1; ++k) {
+                const float4 v = reinterpret_cast<const float4*>(slab + (long long)k * n)[i];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
         }
-        reinterpret_cast<float4*>(out)[i] = s;
+        part[y][x] = s;
+        __syncthreads();
+        if (y == 0 && i < n4) {
+            float4 t = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { t.x += part[q][x].x; t.y += part[q][x].y; t.z += part[q][x].z; t.w += part[q][x].w; }
+            reinterpret_cast<float4*>(out)[i] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -272,12 +289,12 @@ extern "C" int gmt_wgrad(const float* dA, long long lda, const float* X, long lo
     GMT_LAUNCH_CHECK();
     const long long n = (long long)N * I;
     if ((n % 4) == 0 && (((uintptr_t)dW) & 15) == 0)
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gmt_grid_1d(n / 4, 256)), dim3(256), 0, stream, slab, dW, n, ks, accumulate);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gmt_grid_1d(n / 4, 64)), dim3(256), 0, stream, slab, dW, n, ks, accumulate);
     else
         hipLaunchKernelGGL(slab_reduce_scalar_kernel, dim3(gmt_grid_1d(n, 256)), dim3(256), 0, stream, slab, dW, n, ks, accumulate);
     GMT_LAUNCH_CHECK();
     if (db) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gmt_grid_1d(N / 4, 256)), dim3(256), 0, stream, db_slab, db,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gmt_grid_1d(N / 4, 64)), dim3(256), 0, stream, db_slab, db,
                            (long long)N, ks, accumulate);
         GMT_LAUNCH_CHECK();
     }

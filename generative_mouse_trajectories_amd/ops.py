@@ -480,7 +480,7 @@ class GenRolloutFn(torch.autograd.Function):
         dyp = d_ypre.view(T * B, HH)
         d_w1, d_b1 = wgrad(dyp, h1v, want_db=True)
         dov = d_o.view(T * B, 3)
-        d_w2 = torch.mm(dov.t(), y.view(T * B, HH))
+        d_w2 = wgrad(y.view(T * B, HH), dov)[0].t()                    # [3,HH] via its transpose: N = HH, skinny X = d_o
         d_b2 = dov.sum(0)
         d_init = d_in0.sum(0).reshape(ctx.init_shape)
         return (d_g0, d_w_u, d_w_hh0, d_w_ih1, d_w_hh1, d_bias1, d_w1, d_b1, d_w2, d_b2, d_init,
