@@ -51,15 +51,16 @@ def synthetic_batch(B, T, seed, device):
     return {k: v.to(device) for k, v in b.items()}
 
 
-def cpu_baseline(threads: int):
+def cpu_baseline(threads: int, B: int = 128):
     """The CPU oracle (oracle/gan_oracle.py, pinned to the reference by tests/golden) timed on
-    this host: one D step with GP, one without, one G step on a reduced batch; amortised like
-    the GPU metric (GP every 4th D step)."""
+    this host, SURVEY.md section 8d: same synthetic batch at a reduced B, dropout on, one warm-up
+    iteration, then 4 iterations (D steps 0..3: the first carries the gradient penalty) so the GP
+    cost is amortised exactly as in the GPU metric."""
     from oracle import gan_oracle as O
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     import paramgen as PG
     torch.set_num_threads(threads)
-    B, T = 64, T_STEPS
+    T = T_STEPS
     cfg = O.OracleConfig(latent_dim=LATENT, generator_hidden_dim=HID, discriminator_hidden_dim=HID)
     Pg = {k: torch.from_numpy(v) for k, v in PG.make_generator_params(cfg, 1).items()}
     pd, bd = PG.make_discriminator_params(cfg, 2)
@@ -67,22 +68,24 @@ def cpu_baseline(threads: int):
     Bd = {k: torch.from_numpy(v) for k, v in bd.items()}
     batch = synthetic_batch(B, T, 1234, 'cpu')
     gen = torch.Generator().manual_seed(0)
-    z = torch.randn(B, LATENT, generator=gen)
     b = max(1, -(-B // 4))
-    noise = {'z': z, 'gp_idx': torch.randperm(B, generator=gen), 'alpha': torch.rand(b, generator=gen)}
     og, od = {}, {}
+
+    def iteration(d_step):
+        z = torch.randn(B, LATENT, generator=gen)
+        noise = {'z': z, 'gp_idx': torch.randperm(B, generator=gen), 'alpha': torch.rand(b, generator=gen)}
+        O.discriminator_step(Pg, Pd, Bd, od, batch, noise, cfg, d_step, dropout=True, gen=gen)
+        O.generator_step(Pg, Pd, Bd, og, batch, {'z': torch.randn(B, LATENT, generator=gen)}, cfg, [False] * T, 0.0,
+                         dropout=True, gen=gen)
+
+    iteration(1)                                    # warm-up (no GP)
     t0 = time.perf_counter()
-    O.discriminator_step(Pg, Pd, Bd, od, batch, noise, cfg, 0, dropout=True, gen=gen)      # with GP
-    t1 = time.perf_counter()
-    O.discriminator_step(Pg, Pd, Bd, od, batch, noise, cfg, 1, dropout=True, gen=gen)      # without GP
-    t2 = time.perf_counter()
-    O.generator_step(Pg, Pd, Bd, og, batch, {'z': z}, cfg, [False] * T, 0.0, dropout=True, gen=gen)
-    t3 = time.perf_counter()
-    t_iter = ((t1 - t0) + 3 * (t2 - t1)) / 4 + (t3 - t2)
-    return {'value': B / t_iter, 'unit': 'trajectories/s', 'cores': threads, 'kind': 'port',
-            'sample': f'oracle (plain PyTorch CPU restatement of RecurrentGAN.py:913-1118), B={B}, T={T}, H=128/128, '
-                      f'dropout on: 1 D step with GP {t1 - t0:.1f}s, 1 without {t2 - t1:.1f}s, 1 G step {t3 - t2:.1f}s, '
-                      'amortised GP every 4th step'}
+    for d_step in range(4):
+        iteration(d_step)
+    dt = time.perf_counter() - t0
+    return {'value': 4 * B / dt, 'unit': 'trajectories/s', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle (plain PyTorch CPU restatement of RecurrentGAN.py:913-1118), B={B}, T={T}, H=128/128, dropout on: '
+                      f'1 warm-up + 4 iterations (D step + G step; GP on the first) in {dt:.1f}s'}
 
 
 def main():
@@ -92,6 +95,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--batch', type=int, default=B_LOCAL)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true', help='run the two generator rollouts of an iteration one after the other')
     ap.add_argument('--cpu-threads', type=int, default=16)
     args = ap.parse_args()
 
@@ -120,6 +124,7 @@ def main():
         tr.world_size = 2                   # take the all-reduce branch (a sum over one rank)
         tr.g_optimizer.grad_scale = tr.d_optimizer.grad_scale = 1.0
     tr.epoch = cfg.teacher_forcing_decay_epochs     # steady state: teacher-forcing ratio 0 (fully autoregressive)
+    tr.overlap_g_forward = not args.no_overlap      # G-step rollout launched beside the D-step rollout (2 x 128 workgroups)
     G.train(); D.train()
     torch.manual_seed(1234 + rank)                  # per-rank noise
     batch = synthetic_batch(args.batch, T_STEPS, 1234 + rank, dev)

@@ -185,6 +185,12 @@ class Trainer:
         self.patience_counter = 0
         self.epoch = 0
         self.d_step = 0
+        # launch the next generator step's forward rollout beside the D step's (see _launch_speculative_g_forward);
+        # off by default so that the step functions stay independent calls with the reference's RNG draw order
+        self.overlap_g_forward = False
+        self._side = None
+        self._spec = None
+        self._g_version = 0
 
     # ---- helpers ---------------------------------------------------------------------
     def get_teacher_forcing_ratio(self) -> float:
@@ -203,6 +209,30 @@ class Trainer:
                 batch['sequences'].to(d, non_blocking=True), batch['lengths'].to(d, non_blocking=True))
 
     # ---- discriminator step (RecurrentGAN.py:913-1029) ------------------------------
+    def _launch_speculative_g_forward(self, real_batch, starts, ends, sequences, lengths, tf_mask=None) -> None:
+        """The generator step that follows this D step runs G with the weights G has NOW (only D is
+        updated in between), on its own noise.  At B = 4096 a rollout is 128 workgroups - half the CUs -
+        so that forward is launched here on a second stream, beside the D step's no-grad rollout, and
+        train_generator_step picks it up if nothing it depends on changed (same batch object, same G
+        version, same teacher-forcing decisions, no injected z)."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        T = sequences.shape[1]
+        tf_ratio = self.get_teacher_forcing_ratio()
+        if tf_mask is None:
+            tf_mask = [torch.rand(1).item() < tf_ratio for _ in range(T)]
+        tf_mask = [bool(b) for b in tf_mask]
+        with torch.cuda.stream(self._side):
+            z = torch.randn(sequences.shape[0], self.config.latent_dim, device=self.device)
+            out = self.generator(starts, ends, z, target_sequences=sequences, target_lengths=lengths,
+                                 teacher_forcing_ratio=tf_ratio, tf_mask=tf_mask)
+        for t_ in (starts, ends, sequences, lengths):
+            t_.record_stream(self._side)
+        self._spec = {'batch': real_batch, 'g_version': self._g_version, 'tf_ratio': tf_ratio, 'tf_mask': tf_mask, 'out': out,
+                      'z': z}
+
     def train_discriminator_step(self, real_batch: Dict, noise: Optional[Dict] = None) -> Dict[str, float]:
         noise = noise or {}
         cfg = self.config
@@ -213,6 +243,8 @@ class Trainer:
         real_dts_padded = F.pad(sequences[:, :, 2], (1, 0), value=0.001)
         z = noise.get('z')
         z = torch.randn(batch_size, cfg.latent_dim, device=self.device) if z is None else z.to(self.device)
+        if self.overlap_g_forward and self.device.type == 'cuda' and (self.d_step + 1) % max(1, cfg.n_critic) == 0:
+            self._launch_speculative_g_forward(real_batch, starts, ends, sequences, lengths, noise.get('g_tf_mask'))
         with torch.no_grad():
             fake_sequences, fake_lengths = self.generator(starts, ends, z, target_sequences=sequences,
                                                           target_lengths=lengths, teacher_forcing_ratio=0.0,
@@ -254,13 +286,22 @@ class Trainer:
         self.g_optimizer.zero_grad()
         starts, ends, sequences, lengths = self._to_dev(real_batch)
         batch_size, T = sequences.shape[0], sequences.shape[1]
-        z = noise.get('z')
-        z = torch.randn(batch_size, cfg.latent_dim, device=self.device) if z is None else z.to(self.device)
         tf_ratio = self.get_teacher_forcing_ratio()
         tf_mask = noise.get('tf_mask')
-        fake_sequences, fake_lengths = self.generator(starts, ends, z, target_sequences=sequences,
-                                                      target_lengths=lengths, teacher_forcing_ratio=tf_ratio,
-                                                      tf_mask=tf_mask)
+        spec, self._spec = self._spec, None
+        if (spec is not None and spec['batch'] is real_batch and spec['g_version'] == self._g_version
+                and 'z' not in noise and spec['tf_ratio'] == tf_ratio
+                and (tf_mask is None or [bool(b) for b in tf_mask] == spec['tf_mask'])):
+            # the rollout of this step was launched beside the D step's no-grad rollout (same G weights)
+            torch.cuda.current_stream().wait_stream(self._side)
+            fake_sequences, fake_lengths = spec['out']
+            fake_sequences.record_stream(torch.cuda.current_stream())
+        else:
+            z = noise.get('z')
+            z = torch.randn(batch_size, cfg.latent_dim, device=self.device) if z is None else z.to(self.device)
+            fake_sequences, fake_lengths = self.generator(starts, ends, z, target_sequences=sequences,
+                                                          target_lengths=lengths, teacher_forcing_ratio=tf_ratio,
+                                                          tf_mask=tf_mask)
         fake_deltas = fake_sequences[:, :, :2]
         fake_trajectories = trajectory_to_absolute(starts, fake_deltas)
         fake_dts_padded = F.pad(fake_sequences[:, :, 2], (1, 0), value=0.001)
@@ -288,6 +329,7 @@ class Trainer:
         total_loss.backward()
         self._allreduce(self.g_flat)
         self.g_optimizer.step()
+        self._g_version += 1
         vals = torch.stack([g_loss.detach(), endpoint_loss.detach(), direction_loss.detach(),
                             fake_score.detach().mean()]).tolist()
         return {'g_loss': vals[0], 'g_endpoint_loss': vals[1], 'g_direction_loss': vals[2],
@@ -337,6 +379,8 @@ class Trainer:
         checkpoint = torch.load(path, map_location=self.device, weights_only=True)
         self.epoch = checkpoint['epoch']
         self.generator.load_state_dict(checkpoint['generator_state_dict'])
+        self._g_version += 1
+        self._spec = None
         self.discriminator.load_state_dict(checkpoint['discriminator_state_dict'])
         self.g_optimizer.load_state_dict(checkpoint['g_optimizer_state_dict'])
         self.d_optimizer.load_state_dict(checkpoint['d_optimizer_state_dict'])

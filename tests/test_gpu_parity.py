@@ -178,3 +178,43 @@ def test_generator_fused_dropout_matches_oracle_with_same_mask(over, B, T):
     gr = torch.autograd.grad((ref * w).sum(), list(Pg.values()))
     for (k, p), g_ref in zip(G.named_parameters(), gr):
         H.assert_close(p.grad, g_ref, 2e-4, f'G bwd with dropout {k}')
+
+
+def test_overlapped_generator_forward_is_the_same_step():
+    """Trainer.overlap_g_forward launches the G step's rollout during the D step (second stream).
+    With the noise it drew fed to an ordinary trainer, both give the same G step."""
+    import copy
+    import generative_mouse_trajectories_amd as gmt
+    cfg = gmt.Config()
+    cfg.latent_dim, cfg.generator_hidden_dim, cfg.discriminator_hidden_dim = 16, 64, 64
+    cfg.lstm_dropout, cfg.head_dropout = 0.0, 0.0
+    torch.manual_seed(3)
+    G, D = gmt.Generator(cfg), gmt.Discriminator(cfg)
+    G2, D2 = copy.deepcopy(G), copy.deepcopy(D)
+    dev = torch.device('cuda:0')
+    tr1 = gmt.Trainer(G, D, cfg, dev, log_dir='/tmp/gmt_runs_t1')
+    tr2 = gmt.Trainer(G2, D2, cfg, dev, log_dir='/tmp/gmt_runs_t2')
+    tr1.overlap_g_forward = True
+    B, T = 96, 20
+    g = torch.Generator().manual_seed(11)
+    deltas = torch.randn(B, T, 2, generator=g) * 0.01
+    starts = torch.rand(B, 2, generator=g)
+    batch = {'starts': starts.to(dev), 'ends': (starts + deltas.sum(1)).to(dev),
+             'sequences': torch.cat([deltas, torch.rand(B, T, 1, generator=g) * 0.02 + 0.004], -1).to(dev),
+             'lengths': torch.randint(3, T + 1, (B,), generator=g).sort(descending=True).values.to(dev)}
+    for it in range(2):
+        nd = {'z': torch.randn(B, cfg.latent_dim, generator=g), 'gp_idx': torch.randperm(B, generator=g),
+              'alpha': torch.rand(-(-B // 4), generator=g)}
+        r1 = tr1.train_discriminator_step(batch, dict(nd))
+        spec = tr1._spec
+        assert spec is not None
+        zs, mask = spec['z'].clone(), list(spec['tf_mask'])
+        r2 = tr2.train_discriminator_step(batch, dict(nd))
+        for k in r1:
+            assert abs(r1[k] - r2[k]) <= 1e-6 * max(1.0, abs(r2[k])), (k, r1[k], r2[k])
+        g1 = tr1.train_generator_step(batch)
+        assert tr1._spec is None
+        g2 = tr2.train_generator_step(batch, {'z': zs, 'tf_mask': mask})
+        for k in g1:
+            assert abs(g1[k] - g2[k]) <= 1e-6 * max(1.0, abs(g2[k])), (k, g1[k], g2[k])
+    H.assert_close(tr1.g_flat.flat, tr2.g_flat.flat, 1e-6, 'G parameters after two overlapped iterations')
