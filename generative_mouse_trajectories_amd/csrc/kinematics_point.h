@@ -11,6 +11,21 @@
 #  endif
 #endif
 
+#ifdef __HIPCC__
+#  define GMT_HDM __host__ __device__ __forceinline__
+#else
+#  define GMT_HDM inline
+#endif
+
+// a / b: IEEE division on the host (reference arithmetic of the CPU checks); on the device one v_rcp_f32 and a
+// multiply (<= 1.5 ulp; the parity budget of these features is 2e-6 relative), which takes the kernels from
+// VALU-bound to HBM-bound
+#if defined(__HIP_DEVICE_COMPILE__)
+#  define GMT_DIV(a, b) __fdividef((a), (b))
+#else
+#  define GMT_DIV(a, b) ((a) / (b))
+#endif
+
 namespace gmt_kin {
 
 struct F2 { float x, y; };
@@ -25,13 +40,13 @@ GMT_HD Pt make_pt(float x, float y, float xp, float yp, float d, bool has_prev, 
     p.dy = has_prev ? y - yp : 0.0f;
     p.td = d + eps;
     p.disp = sqrtf(p.dx * p.dx + p.dy * p.dy + eps);               // RG.py:341
-    p.vel = p.disp / p.td;                                         // RG.py:342
-    p.vx = p.dx / p.td;                                            // RG.py:345-346
-    p.vy = p.dy / p.td;
+    p.vel = GMT_DIV(p.disp, p.td);                                         // RG.py:342
+    p.vx = GMT_DIV(p.dx, p.td);                                            // RG.py:345-346
+    p.vy = GMT_DIV(p.dy, p.td);
     return p;
 }
 
-GMT_HD void kin_fwd_point(long long idx, const float* pos, const float* dts, float* feat, int L, int B, float eps)
+GMT_HD void kin_fwd_vals(long long idx, const float* pos, const float* dts, float (&o)[9], int L, int B, float eps)
 {
     const int t = (int)(idx / B);
     // window t-3 .. t (clamped loads; the has_prev flags zero what does not exist)
@@ -50,18 +65,17 @@ GMT_HD void kin_fwd_point(long long idx, const float* pos, const float* dts, flo
     float acc = 0.f, accp = 0.f, jerk = 0.f, ax = 0.f, ay = 0.f;
     if (t >= 1) {
         float m = (d[3] + d[2]) * 0.5f + eps;                         // RG.py:351
-        acc = (p0.vel - p1.vel) / m;                                  // RG.py:352
-        ax = (p0.vx - p1.vx) / m;                                     // RG.py:363-364
-        ay = (p0.vy - p1.vy) / m;
+        acc = GMT_DIV(p0.vel - p1.vel, m);                               // RG.py:352
+        ax = GMT_DIV(p0.vx - p1.vx, m);                                   // RG.py:363-364
+        ay = GMT_DIV(p0.vy - p1.vy, m);
         if (t >= 2) {
             float mp = (d[2] + d[1]) * 0.5f + eps;
-            accp = (p1.vel - p2.vel) / mp;
-            jerk = (acc - accp) / (m + eps);                          // RG.py:356-357
+            accp = GMT_DIV(p1.vel - p2.vel, mp);
+            jerk = GMT_DIV(acc - accp, m + eps);                       // RG.py:356-357
         }
     }
     float u = p0.vx * p0.vx + p0.vy * p0.vy + eps;
-    float curv = fabsf(p0.vx * ay - p0.vy * ax) / (u * sqrtf(u));     // RG.py:366-368
-    float* o = feat + idx * 9;
+    float curv = GMT_DIV(fabsf(p0.vx * ay - p0.vy * ax), u * sqrtf(u));     // RG.py:366-368
     o[0] = x[3]; o[1] = y[3]; o[2] = p0.dx; o[3] = p0.dy; o[4] = d[3];
     o[5] = fminf(fmaxf(p0.vel, 0.f), 100.f);                          // RG.py:371-374
     o[6] = fminf(fmaxf(acc, -1000.f), 1000.f);
@@ -69,10 +83,20 @@ GMT_HD void kin_fwd_point(long long idx, const float* pos, const float* dts, flo
     o[8] = fminf(fmaxf(curv, 0.f), 100.f);
 }
 
+GMT_HD void kin_fwd_point(long long idx, const float* pos, const float* dts, float* feat, int L, int B, float eps)
+{
+    float o[9];
+    kin_fwd_vals(idx, pos, dts, o, L, B, eps);
+    for (int c = 0; c < 9; ++c) feat[idx * 9 + c] = o[c];
+}
+
 // Backward for point (s, b): gathers d(loss)/d(pos_s), d(loss)/d(dts_s) from the feature
 // gradients of points s .. s+3, recomputing the forward window s-3 .. s+3.
-GMT_HD void kin_bwd_point(long long idx, const float* pos, const float* dts, const float* gfeat,
-                          float* gpos, float* gdts, int L, int B, float eps)
+// `grad(k, c)` returns d(loss)/d(feat[point s+k][c]) for k = 0..3 with s+k <= L-1 (the kernel serves it from
+// LDS, the host simulation from memory); results: (gx, gy) and gd.
+template <class Grad>
+GMT_HD void kin_bwd_vals(long long idx, const float* pos, const float* dts, Grad grad,
+                         float& gx_out, float& gy_out, float& gd_out, int L, int B, float eps)
 {
     const int s = (int)(idx / B);
     // points s-3 .. s+3 -> local index k = tt - (s-3)
@@ -99,9 +123,9 @@ GMT_HD void kin_bwd_point(long long idx, const float* pos, const float* dts, con
         int tt = s - 1 + k;
         bool ok = (tt >= 1) && (tt <= L - 1);
         m[k] = (d[k + 2] + d[k + 1]) * 0.5f + eps;
-        acc[k] = ok ? (P[k + 1].vel - P[k].vel) / m[k] : 0.f;
-        axv[k] = ok ? (P[k + 1].vx - P[k].vx) / m[k] : 0.f;
-        ayv[k] = ok ? (P[k + 1].vy - P[k].vy) / m[k] : 0.f;
+        acc[k] = ok ? GMT_DIV(P[k + 1].vel - P[k].vel, m[k]) : 0.f;
+        axv[k] = ok ? GMT_DIV(P[k + 1].vx - P[k].vx, m[k]) : 0.f;
+        ayv[k] = ok ? GMT_DIV(P[k + 1].vy - P[k].vy, m[k]) : 0.f;
     }
     // feature gradients of tt = s .. s+3 (zero outside the sequence)
     float g[4][9];
@@ -109,9 +133,8 @@ GMT_HD void kin_bwd_point(long long idx, const float* pos, const float* dts, con
     for (int k = 0; k < 4; ++k) {
         int tt = s + k;
         bool ok = tt <= L - 1;
-        const float* gp = gfeat + (idx + (long long)(ok ? k : 0) * B) * 9;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) g[k][c] = ok ? gp[c] : 0.f;
+        for (int c = 0; c < 9; ++c) g[k][c] = ok ? grad(k, c) : 0.f;
     }
     // jerk adjoint Jb[k], tt = s+k (k = 0..3); jerk value jv[k]
     float Jb[4], jv[4];
@@ -119,7 +142,7 @@ GMT_HD void kin_bwd_point(long long idx, const float* pos, const float* dts, con
     for (int k = 0; k < 4; ++k) {
         int tt = s + k;
         bool ok = (tt >= 2) && (tt <= L - 1);
-        float j = ok ? (acc[k + 1] - acc[k]) / (m[k + 1] + eps) : 0.f;
+        float j = ok ? GMT_DIV(acc[k + 1] - acc[k], m[k + 1] + eps) : 0.f;
         jv[k] = j;
         Jb[k] = (ok && j >= -10000.f && j <= 10000.f) ? g[k][7] : 0.f;
     }
@@ -131,8 +154,8 @@ GMT_HD void kin_bwd_point(long long idx, const float* pos, const float* dts, con
         bool ok = (tt >= 1) && (tt <= L - 1);
         float a = acc[k + 1];
         float v = (a >= -1000.f && a <= 1000.f) ? g[k][6] : 0.f;
-        v += Jb[k] / (m[k + 1] + eps);
-        v -= Jb[k + 1] / (m[k + 2] + eps);      // Jb is zero when tt+1 is outside
+        v += GMT_DIV(Jb[k], m[k + 1] + eps);
+        v -= GMT_DIV(Jb[k + 1], m[k + 2] + eps);     // Jb is zero when tt+1 is outside
         Ab[k] = ok ? v : 0.f;
     }
     // curvature adjoints at tt = s+k (k = 0..2): qb, ub, axb, ayb
@@ -148,11 +171,11 @@ GMT_HD void kin_bwd_point(long long idx, const float* pos, const float* dts, con
         float su = sqrtf(u);
         float s3 = u * su;
         float cross = fabsf(q);
-        float curv = cross / s3;
+        float curv = GMT_DIV(cross, s3);
         float Cb = (ok && curv >= 0.f && curv <= 100.f) ? g[k][8] : 0.f;
         float sgn = q > 0.f ? 1.f : (q < 0.f ? -1.f : 0.f);
-        qb[k] = Cb * sgn / s3;
-        ub[k] = -Cb * curv * 1.5f / u;          // d(cross/u^1.5)/du = -1.5 * curv / u
+        qb[k] = GMT_DIV(Cb * sgn, s3);
+        ub[k] = GMT_DIV(-Cb * curv * 1.5f, u);         // d(cross/u^1.5)/du = -1.5 * curv / u
         bool okA = ok && tt >= 1;
         axb[k] = okA ? -qb[k] * p.vy : 0.f;
         ayb[k] = okA ? qb[k] * p.vx : 0.f;
@@ -166,22 +189,36 @@ GMT_HD void kin_bwd_point(long long idx, const float* pos, const float* dts, con
         const Pt& p = P[k + 2];
         float ax = axv[k + 1], ay = ayv[k + 1];
         float Vb = (p.vel >= 0.f && p.vel <= 100.f) ? g[k][5] : 0.f;
-        Vb += Ab[k] / m[k + 1];                  // Ab is zero for tt < 1
-        Vb -= Ab[k + 1] / m[k + 2];              // zero when tt+1 outside
-        float VXb = qb[k] * ay + 2.f * ub[k] * p.vx + axb[k] / m[k + 1] - axb[k + 1] / m[k + 2];
-        float VYb = -qb[k] * ax + 2.f * ub[k] * p.vy + ayb[k] / m[k + 1] - ayb[k + 1] / m[k + 2];
-        float dispb = Vb / p.td;
-        float tdb = -Vb * p.vel / p.td - VXb * p.vx / p.td - VYb * p.vy / p.td;
-        dxb[k] = ok ? (g[k][2] + VXb / p.td + dispb * p.dx / p.disp) : 0.f;
-        dyb[k] = ok ? (g[k][3] + VYb / p.td + dispb * p.dy / p.disp) : 0.f;
+        Vb += GMT_DIV(Ab[k], m[k + 1]);               // Ab is zero for tt < 1
+        Vb -= GMT_DIV(Ab[k + 1], m[k + 2]);            // zero when tt+1 outside
+        float VXb = qb[k] * ay + 2.f * ub[k] * p.vx + GMT_DIV(axb[k], m[k + 1]) - GMT_DIV(axb[k + 1], m[k + 2]);
+        float VYb = -qb[k] * ax + 2.f * ub[k] * p.vy + GMT_DIV(ayb[k], m[k + 1]) - GMT_DIV(ayb[k + 1], m[k + 2]);
+        float dispb = GMT_DIV(Vb, p.td);
+        float tdb = GMT_DIV(-Vb * p.vel, p.td) - GMT_DIV(VXb * p.vx, p.td) - GMT_DIV(VYb * p.vy, p.td);
+        dxb[k] = ok ? (g[k][2] + GMT_DIV(VXb, p.td) + GMT_DIV(dispb * p.dx, p.disp)) : 0.f;
+        dyb[k] = ok ? (g[k][3] + GMT_DIV(VYb, p.td) + GMT_DIV(dispb * p.dy, p.disp)) : 0.f;
         bool okM = ok && tt >= 1;
-        mb[k] = okM ? (-Ab[k] * acc[k + 1] / m[k + 1] - Jb[k] * jv[k] / (m[k + 1] + eps)
-                       - axb[k] * ax / m[k + 1] - ayb[k] * ay / m[k + 1]) : 0.f;
+        mb[k] = okM ? (GMT_DIV(-Ab[k] * acc[k + 1], m[k + 1]) - GMT_DIV(Jb[k] * jv[k], m[k + 1] + eps)
+                       - GMT_DIV(axb[k] * ax, m[k + 1]) - GMT_DIV(ayb[k] * ay, m[k + 1])) : 0.f;
         if (k == 0) tdb0 = tdb;
     }
     float gx = g[0][0] + (s >= 1 ? dxb[0] : 0.f) - dxb[1];
     float gy = g[0][1] + (s >= 1 ? dyb[0] : 0.f) - dyb[1];
     float gd = g[0][4] + tdb0 + 0.5f * (mb[0] + mb[1]);
+    gx_out = gx; gy_out = gy; gd_out = gd;
+}
+
+struct GradFromMemory {
+    const float* gfeat; long long idx; int B;
+    GMT_HDM float operator()(int k, int c) const { return gfeat[(idx + (long long)k * B) * 9 + c]; }
+};
+
+GMT_HD void kin_bwd_point(long long idx, const float* pos, const float* dts, const float* gfeat,
+                          float* gpos, float* gdts, int L, int B, float eps)
+{
+    float gx, gy, gd;
+    GradFromMemory gm{gfeat, idx, B};
+    kin_bwd_vals(idx, pos, dts, gm, gx, gy, gd, L, B, eps);
     gpos[idx * 2] = gx; gpos[idx * 2 + 1] = gy;
     gdts[idx] = gd;
 }

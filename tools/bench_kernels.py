@@ -49,10 +49,13 @@ def main():
     posb = torch.rand(L, Bb, 2, device=dev); dtsb = torch.rand(L, Bb, device=dev) * 0.02 + 0.004
     t = timed(lambda: ops.kinematics_tm(posb, dtsb), reps=10)
     print(f'kinematics fwd  B={Bb} L={L}: {t * 1e6:8.1f} us  {48 * Bb * L / t / 1e9:8.1f} GB/s  ({48 * Bb * L / t / 1e9 / PEAK_HBM:.1%})')
-    pb = posb.requires_grad_(True); db = dtsb.requires_grad_(True)
-    f = ops.kinematics_tm(pb, db); g = torch.randn_like(f)
-    t = timed(lambda: torch.autograd.grad(f, (pb, db), g, retain_graph=True), reps=10)
+    from generative_mouse_trajectories_amd import _lib as L_
+    gfeat = torch.randn(L, Bb, 9, device=dev); gpos = torch.empty(L, Bb, 2, device=dev); gdts = torch.empty(L, Bb, device=dev)
+    t = timed(lambda: L_.call('gmt_kinematics_bwd', L_.ptr(posb), L_.ptr(dtsb), L_.ptr(gfeat), L_.ptr(gpos), L_.ptr(gdts),
+                              L, Bb, 1e-8, L_.stream()), reps=10)
     print(f'kinematics bwd  B={Bb} L={L}: {t * 1e6:8.1f} us  {60 * Bb * L / t / 1e9:8.1f} GB/s  ({60 * Bb * L / t / 1e9 / PEAK_HBM:.1%})')
+    pb = db = f = g = None
+    del gfeat, gpos, gdts
     del posb, dtsb, pb, db, f, g
 
     # --- Adam: 28 B/parameter
