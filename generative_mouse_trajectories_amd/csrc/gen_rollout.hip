@@ -128,7 +128,7 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
             if constexpr (RES0) gmt_mma_resident<4, KS, KR>(acc, h0T + (size_t)cur * H * GMT_LDA, wr0, lane, wl);
             else gmt_mma_stream<4>(acc, h0T + (size_t)cur * H * GMT_LDA, whh0, H, lane);
             float* hn = h0T + (size_t)(cur ^ 1) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
-            float* sg = TRAIN ? a.gates0 + rs * (4 * H) + col : nullptr;
+            float* sg = TRAIN ? a.gates0 + rs * (4 * H) + 4 * col : nullptr;
             float* sc = TRAIN ? a.c0_all + rs * H + col : nullptr;
             float* sh = TRAIN ? a.h0_all + rs * H + col : nullptr;
             float* shd = TRAIN ? a.h0d_all + rs * H + col : nullptr;
@@ -149,7 +149,7 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
                     if (TRAIN) shd[(size_t)mr * H] = hdv;
                 }
                 if (TRAIN) {
-                    float* q = sg + (size_t)mr * (4 * H); q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og;
+                    gmt_st4(sg + (size_t)mr * (4 * H), ig, fg, gg, og);
                     sc[(size_t)mr * H] = cn;
                     sh[(size_t)mr * H] = hv;
                 }
@@ -168,7 +168,7 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
             gmt_mma_stream<4>(acc, h1T + (size_t)(H1S ? 0 : cur) * H * GMT_LDA, whh1, H, lane);
             if constexpr (H1S) __syncthreads();
             float* hn = h1T + (size_t)(H1S ? 0 : (cur ^ 1)) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
-            float* sg = TRAIN ? a.gates1 + rs * (4 * H) + col : nullptr;
+            float* sg = TRAIN ? a.gates1 + rs * (4 * H) + 4 * col : nullptr;
             float* sc = TRAIN ? a.c1_all + rs * H + col : nullptr;
             float* sh = TRAIN ? a.h1_all + rs * H + col : nullptr;
 #pragma unroll
@@ -181,7 +181,7 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
                 c1[r] = cn;
                 hn[mr] = hv;
                 if (TRAIN) {
-                    float* q = sg + (size_t)mr * (4 * H); q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og;
+                    gmt_st4(sg + (size_t)mr * (4 * H), ig, fg, gg, og);
                     sc[(size_t)mr * H] = cn;
                     sh[(size_t)mr * H] = hv;
                 }
@@ -319,15 +319,15 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
     static_assert(NT % HH == 0, "B2 thread map");
     auto fetch_row1 = [&](int t, int r) {
         const int mr = (r & 3) + 8 * (r >> 2);
-        const float* q = a.gates1 + (((size_t)t * B + lane_row) + mr) * (4 * H) + col;
-        g1[0][r] = q[0]; g1[1][r] = q[H]; g1[2][r] = q[2 * H]; g1[3][r] = q[3 * H];
+        const float4 q = gmt_ld4(a.gates1 + (((size_t)t * B + lane_row) + mr) * (4 * H) + 4 * col);
+        g1[0][r] = q.x; g1[1][r] = q.y; g1[2][r] = q.z; g1[3][r] = q.w;
         const int tp = t > 0 ? t - 1 : 0;              // (t = 0: c_{-1} = 0 is selected at use)
         cp1[r] = a.c1_all[(((size_t)tp * B + lane_row) + mr) * H + col];
     };
     auto fetch_row0 = [&](int t, int r) {
         const int mr = (r & 3) + 8 * (r >> 2);
-        const float* q = a.gates0 + (((size_t)t * B + lane_row) + mr) * (4 * H) + col;
-        g0[0][r] = q[0]; g0[1][r] = q[H]; g0[2][r] = q[2 * H]; g0[3][r] = q[3 * H];
+        const float4 q = gmt_ld4(a.gates0 + (((size_t)t * B + lane_row) + mr) * (4 * H) + 4 * col);
+        g0[0][r] = q.x; g0[1][r] = q.y; g0[2][r] = q.z; g0[3][r] = q.w;
         const int tp = t > 0 ? t - 1 : 0;
         cp0[r] = a.c0_all[(((size_t)tp * B + lane_row) + mr) * H + col];
     };
@@ -397,7 +397,7 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][r] = dh1[r];
             gmt_mma_stream<1>(acc, dyT, w1T, HH, lane);
-            float* gp = a.gates1 + rs * (4 * H) + col;
+            float* gp = a.gates1 + rs * (4 * H) + 4 * col;
             float* dl = daT + col * GMT_LDA + 4 * hi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -407,7 +407,7 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
                 float dai, daf, dag, dao;
                 cell_bwd(acc[0][r], dc1[r], g1[0][r], g1[1][r], g1[2][r], g1[3][r], cn1[r], cp, dai, daf, dag, dao);
                 cn1[r] = cp1[r];
-                q[0] = dai; q[H] = daf; q[2 * H] = dag; q[3 * H] = dao;
+                gmt_st4(q, dai, daf, dag, dao);
                 dl[0 * H * GMT_LDA + mr] = dai; dl[1 * H * GMT_LDA + mr] = daf;
                 dl[2 * H * GMT_LDA + mr] = dag; dl[3 * H * GMT_LDA + mr] = dao;
             }
@@ -436,7 +436,7 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
         GMT_PH(4);
         // ---- B5: layer-0 cell backward -> da0
         {
-            float* gp = a.gates0 + rs * (4 * H) + col;
+            float* gp = a.gates0 + rs * (4 * H) + 4 * col;
             float* dl = daT + col * GMT_LDA + 4 * hi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -446,7 +446,7 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
                 float dai, daf, dag, dao;
                 cell_bwd(acc2[1][r], dc0[r], g0[0][r], g0[1][r], g0[2][r], g0[3][r], cn0[r], cp, dai, daf, dag, dao);
                 cn0[r] = cp0[r];
-                q[0] = dai; q[H] = daf; q[2 * H] = dag; q[3 * H] = dao;
+                gmt_st4(q, dai, daf, dag, dao);
                 dl[0 * H * GMT_LDA + mr] = dai; dl[1 * H * GMT_LDA + mr] = daf;
                 dl[2 * H * GMT_LDA + mr] = dag; dl[3 * H * GMT_LDA + mr] = dao;
             }

@@ -105,12 +105,12 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
 
         const float* ho = hT + (size_t)cur * H * GMT_LDA + col * GMT_LDA + 4 * hi;
         float* hn = hT + (size_t)(cur ^ 1) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
-        const float* gp = gates + rs * (4 * H) + col;
+        const float* gp = gates + rs * (4 * H) + 4 * col;
         const float* cn_p = c_all + rs * H + col;
         const float* cp_p = c_all + rsp * H + col;
         const float* dct_p = dct_all + rs * H + col;
         const float* dht_p = dht_all + rs * H + col;
-        float* gg_p = g_gates + rs * (4 * H) + col;
+        float* gg_p = g_gates + rs * (4 * H) + 4 * col;
         float* gc_p = g_c + rs * H + col;
         float* gcp_p = g_c + rsp * H + col;
         float* hh_p = hhat_all ? hhat_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col : nullptr;
@@ -122,8 +122,8 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
             float o_gi = 0.f, o_gf = 0.f, o_gg = 0.f, o_go = 0.f, o_gc = 0.f, o_hh = 0.f;
             float hnew = ho[mr];
             if (act) {
-                const float* q = gp + (size_t)mr * (4 * H);
-                const float ig = q[0], fg = q[H], gg = q[2 * H], og = q[3 * H];
+                const float4 q = gmt_ld4(gp + (size_t)mr * (4 * H));
+                const float ig = q.x, fg = q.y, gg = q.z, og = q.w;
                 const float cn = cn_p[(size_t)mr * H];
                 const bool has_prev = dir ? (tp < ln) : (tp >= 0);
                 const float cp = has_prev ? cp_p[(size_t)mr * H] : 0.f;
@@ -151,8 +151,7 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
                 if (has_prev) gcp_p[(size_t)mr * H] += adf * dct;      // c_{prev} also enters df of this step
             }
             hn[mr] = hnew;
-            float* w = gg_p + (size_t)mr * (4 * H);
-            w[0] = o_gi; w[H] = o_gf; w[2 * H] = o_gg; w[3 * H] = o_go;
+            gmt_st4(gg_p + (size_t)mr * (4 * H), o_gi, o_gf, o_gg, o_go);
             gc_p[(size_t)mr * H] = o_gc;
             if (hh_p) hh_p[(size_t)mr * (ndir * H)] = o_hh;
         }
@@ -166,8 +165,7 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int mr = (r & 3) + 8 * (r >> 2);
-            float* w = g_gates + (rs + mr) * (4 * H) + col;
-            w[0] = 0.f; w[H] = 0.f; w[2 * H] = 0.f; w[3 * H] = 0.f;
+            gmt_st4(g_gates + (rs + mr) * (4 * H) + 4 * col, 0.f, 0.f, 0.f, 0.f);
             g_c[(rs + mr) * H + col] = 0.f;
             if (hhat_all) hhat_all[((size_t)t * B + lane_row + mr) * (ndir * H) + dir * H + col] = 0.f;
         }

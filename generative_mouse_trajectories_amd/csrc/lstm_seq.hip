@@ -159,12 +159,12 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][r] = bz[g];
         } else {
-            const float* pp = pregates + rs * (4 * H) + col;
+            const float* pp = pregates + rs * (4 * H) + 4 * col;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[g][r] = pp[(size_t)((r & 3) + 8 * (r >> 2)) * (4 * H) + g * H];
+            for (int r = 0; r < 16; ++r) {
+                const float4 v = gmt_ld4(pp + (size_t)((r & 3) + 8 * (r >> 2)) * (4 * H));
+                acc[0][r] = v.x; acc[1][r] = v.y; acc[2][r] = v.z; acc[3][r] = v.w;
+            }
         }
         if constexpr (RES) gmt_mma_resident<4, KS, KR>(acc, hT, wr, lane, wl);
         else gmt_mma_stream<4>(acc, hT, whh, H, lane);
@@ -182,7 +182,7 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
             GMT_PH(0);
         }
 
-        float* gp = gates ? gates + rs * (4 * H) + col : nullptr;
+        float* gp = gates ? gates + rs * (4 * H) + 4 * col : nullptr;
         float* cp = c_all ? c_all + rs * H + col : nullptr;
         float* hp = h_all ? h_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col : nullptr;
         // the cell update; MASKED = some row of the tile is already past its length at step t
@@ -209,13 +209,13 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
                     const bool act = (am >> r) & 1u;
                     c[r] = act ? cn : c[r];
                     hs[mr] = act ? hv : hs[mr];
-                    if (FULL || gp) { q[0] = act ? ig : 0.f; q[H] = act ? fg : 0.f; q[2 * H] = act ? gg : 0.f; q[3 * H] = act ? og : 0.f; }
+                    if (FULL || gp) gmt_st4(q, act ? ig : 0.f, act ? fg : 0.f, act ? gg : 0.f, act ? og : 0.f);
                     if (FULL || cp) cp[(size_t)mr * H] = act ? cn : 0.f;
                     if (FULL || hp) hp[(size_t)mr * (ndir * H)] = act ? hv : 0.f;
                 } else {
                     c[r] = cn;
                     hs[mr] = hv;
-                    if (FULL || gp) { q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og; }   // FULL: no per-row branches
+                    if (FULL || gp) gmt_st4(q, ig, fg, gg, og);                                // FULL: no per-row branches
                     if (FULL || cp) cp[(size_t)mr * H] = cn;
                     if (FULL || hp) hp[(size_t)mr * (ndir * H)] = hv;
                 }
@@ -324,8 +324,8 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
         const bool tp_ok = (tp >= 0) && (tp < L);
         const size_t rs = ((size_t)dir * L + t) * B + lane_row;
         const int mr = (r & 3) + 8 * (r >> 2);
-        const float* q = gates + (rs + mr) * (4 * H) + col;
-        pg[0][r] = q[0]; pg[1][r] = q[H]; pg[2][r] = q[2 * H]; pg[3][r] = q[3 * H];
+        const float4 q = gmt_ld4(gates + (rs + mr) * (4 * H) + 4 * col);
+        pg[0][r] = q.x; pg[1][r] = q.y; pg[2][r] = q.z; pg[3][r] = q.w;
         const float cpv = c_all[(((size_t)dir * L + (tp_ok ? tp : t)) * B + lane_row + mr) * H + col];
         pcp[r] = tp_ok ? cpv : 0.f;
         pdy[r] = dh_all ? dh_all[((size_t)t * B + lane_row + mr) * (ndir * H) + dir * H + col] : 0.f;
@@ -346,10 +346,10 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
         const int tp = dir ? t + 1 : t - 1;            // the step the forward pass visited before t
         GMT_PH(5);
         const size_t rs = ((size_t)dir * L + t) * B + lane_row;
-        float* wp = ((!PLAIN && da_out) ? da_out : gates) + rs * (4 * H) + col;
+        float* wp = ((!PLAIN && da_out) ? da_out : gates) + rs * (4 * H) + 4 * col;
         float* dct_p = (!PLAIN && dct_out) ? dct_out + rs * H + col : nullptr;
         float* dht_p = (!PLAIN && dht_out) ? dht_out + rs * H + col : nullptr;
-        const float* ge_p = (!PLAIN && dgates_extra) ? dgates_extra + rs * (4 * H) + col : nullptr;
+        const float* ge_p = (!PLAIN && dgates_extra) ? dgates_extra + rs * (4 * H) + 4 * col : nullptr;
         const float* ce_p = (!PLAIN && dc_extra) ? dc_extra + rs * H + col : nullptr;
         float* dl = daT + col * GMT_LDA + 4 * hi;      // this lane's slots of the transposed da tile
         f32x16 acc[1];
@@ -382,8 +382,8 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
                 if (!PLAIN && ce_p) dct += ce_p[(size_t)mr * H];
                 float dig = dct * gg, dgg = dct * ig, dfg = dct * cp;
                 if (!PLAIN && ge_p) {
-                    const float* ep = ge_p + (size_t)mr * (4 * H);
-                    dig += ep[0]; dfg += ep[H]; dgg += ep[2 * H]; dog += ep[3 * H];
+                    const float4 ep = gmt_ld4(ge_p + (size_t)mr * (4 * H));
+                    dig += ep.x; dfg += ep.y; dgg += ep.z; dog += ep.w;
                 }
                 dc[r] = act ? dct * fg : dc[r];
                 const float dai = act ? dig * ig * (1.f - ig) : 0.f;
@@ -393,8 +393,7 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
                 acc[0][r] = act ? 0.f : dh[r];         // live row: dh_prev = da W_hh only; frozen row: state passes through
                 cn_c[r] = pcp[r];                      // c of the step processed next
                 // d(pre-activation) replaces the gates (zero at padded steps: the weight-gradient GEMM reads it)
-                float* w = wp + (size_t)mr * (4 * H);
-                w[0] = dai; w[H] = daf; w[2 * H] = dag; w[3 * H] = dao;
+                gmt_st4(wp + (size_t)mr * (4 * H), dai, daf, dag, dao);
                 if (!PLAIN && dct_p) dct_p[(size_t)mr * H] = act ? dct : 0.f;
                 if (!PLAIN && dht_p) dht_p[(size_t)mr * H] = act ? dht : 0.f;
                 dl[0 * H * GMT_LDA + mr] = dai;
@@ -433,11 +432,10 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
     GMT_PH_DUMP;
     // steps [tmax, L) of the tile are padding: zero their d(pre-activation)
     for (int t = tmax; t < L; ++t) {
-        float* gp = ((!PLAIN && da_out) ? da_out : gates) + (((size_t)dir * L + t) * B + lane_row) * (4 * H) + col;
+        float* gp = ((!PLAIN && da_out) ? da_out : gates) + (((size_t)dir * L + t) * B + lane_row) * (4 * H) + 4 * col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float* q = gp + (size_t)((r & 3) + 8 * (r >> 2)) * (4 * H);
-            q[0] = 0.f; q[H] = 0.f; q[2 * H] = 0.f; q[3 * H] = 0.f;
+            gmt_st4(gp + (size_t)((r & 3) + 8 * (r >> 2)) * (4 * H), 0.f, 0.f, 0.f, 0.f);
         }
     }
 }

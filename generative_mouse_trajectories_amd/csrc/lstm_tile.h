@@ -86,6 +86,19 @@ __device__ __forceinline__ void gmt_stream_fetch(float4 (&w)[NG], float (&a)[4],
 // the 4*NG MFMAs of group s4 are issued, so an L2 round trip hides under a whole group.  The
 // scheduling fences keep the compiler from sinking the loads back down to their first use
 // (measured on MI355X: 34 -> 29 ns per MFMA, 28.5 being the register-only rate).
+// Saved gate buffers (activated i,f,g,o; d(pre-activation); their adjoints) are row-major with UNIT-MAJOR
+// columns: element (row, unit, gate) at row*4H + 4*unit + gate.  The four gate values a lane owns for one
+// (row, unit) are one aligned float4, so a wave moves them with one 16-byte access per accumulator row
+// (32 units x 16 B contiguous per row half) instead of four dword accesses 4H bytes apart.  The host
+// permutes the 4H axis of the weights that meet these buffers in a GEMM (ops.gate_perm / gate_unperm).
+__device__ __forceinline__ float4 gmt_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void gmt_st4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+
+// k-groups per stage of the 4-gate streamed loop (tuning knob)
+#ifndef GMT_STREAM_G4
+#define GMT_STREAM_G4 1
+#endif
+
 // One pipeline stage of the streamed contraction = G k-groups (8 k each) = 4*NG*G >= 16 MFMAs:
 // the stage is what one L2 round trip has to hide under.
 template <int NG, int G>
@@ -124,7 +137,7 @@ template <int NG>
 __device__ __forceinline__ void gmt_mma_stream(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
                                                const float4* __restrict__ wpk, int K, int lane)
 {
-    constexpr int G = (NG >= 4) ? 1 : (NG == 2 ? 2 : 4);
+    constexpr int G = (NG >= 4) ? GMT_STREAM_G4 : (NG == 2 ? 2 : 4);
     const int hi = lane >> 5, lo = lane & 31;
     const int ns4 = K >> 3;
     const int nst = ns4 / G;

@@ -25,6 +25,25 @@ def pad_rows(n: int) -> int:
 # ----------------------------------------------------------------------------------------
 # kinematic features (RecurrentGAN.py:315-389), time-major
 # ----------------------------------------------------------------------------------------
+def gate_perm(w: torch.Tensor) -> torch.Tensor:
+    """[4H, ...] in torch's gate-major order (row g*H + unit) -> the unit-major order of the kernels'
+    saved-gate buffers (row 4*unit + g); see csrc/lstm_tile.h."""
+    H = w.shape[0] // 4
+    return w.reshape(4, H, -1).transpose(0, 1).reshape(w.shape).contiguous()
+
+
+def gate_unperm(w: torch.Tensor) -> torch.Tensor:
+    """Inverse of gate_perm along dim 0."""
+    H = w.shape[0] // 4
+    return w.reshape(H, 4, -1).transpose(0, 1).reshape(w.shape).contiguous()
+
+
+def wgrad_gates(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False):
+    """wgrad for a d(pre-activation) buffer (unit-major columns): results in torch's gate-major order."""
+    dW, db = wgrad(dA, X, want_db)
+    return gate_unperm(dW), (None if db is None else gate_unperm(db))
+
+
 class KinematicsFn(torch.autograd.Function):
     """pos [L,B,2], dts [L,B] -> feat [L,B,9]."""
 
@@ -174,7 +193,7 @@ class LSTMLayerFn(torch.autograd.Function):
         else:
             x2 = x.view(L * B, I)
             for d in range(nd):
-                torch.addmm(bias[d], x2, w_ih[d].detach().t(), out=gates[d].view(L * B, 4 * H))
+                torch.addmm(gate_perm(bias[d]), x2, gate_perm(w_ih[d].detach()).t(), out=gates[d].view(L * B, 4 * H))
             L_.call('gmt_lstm_layer_fwd', None, L_.ptr(gates), None, L_.ptr(w_hh_pk), None,
                     L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
                     L, B, I, H, nd, L_.stream(), label='lstm_fwd_pregates')
@@ -202,9 +221,9 @@ class LSTMLayerFn(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = []
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(da[0].view(L * B, 4 * H), w_ih[0])
+            dx = torch.mm(da[0].view(L * B, 4 * H), gate_perm(w_ih[0].detach()))
             for d in range(1, nd):
-                dx.addmm_(da[d].view(L * B, 4 * H), w_ih[d])
+                dx.addmm_(da[d].view(L * B, 4 * H), gate_perm(w_ih[d].detach()))
             dx = dx.view(L, B, I)
         need_w = any(ctx.needs_input_grad[4:])
         if need_w:
@@ -223,11 +242,11 @@ def _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd):
     grads = []
     for d in range(nd):
         da2 = da[d].view(L * B, 4 * H)
-        d_wih, db = wgrad(da2, x2, want_db=True)
+        d_wih, db = wgrad_gates(da2, x2, want_db=True)
         hv = h_all.view(L * B, nd * H)[:, d * H:(d + 1) * H]
         if L > 1:
             # forward direction: h_prev(t) = h[t-1]; reverse: h_prev(t) = h[t+1] (zero beyond the row's length)
-            d_whh, _ = wgrad(da2[B:], hv[:-B]) if d == 0 else wgrad(da2[:-B], hv[B:])
+            d_whh, _ = wgrad_gates(da2[B:], hv[:-B]) if d == 0 else wgrad_gates(da2[:-B], hv[B:])
         else:
             d_whh = torch.zeros_like(w_hh[d])
         grads += [d_wih, d_whh, db, db]
@@ -257,9 +276,9 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
                 L_.ptr(dh_all), L_.ptr(dh_final), None, None, L_.ptr(da), L_.ptr(dct), L_.ptr(dht),
                 L, B, H, nd, L_.stream(), label='lstm_bwd_gp')
-        dx = torch.mm(da[0].view(L * B, 4 * H), w_ih[0].detach())
+        dx = torch.mm(da[0].view(L * B, 4 * H), gate_perm(w_ih[0].detach()))
         for d in range(1, nd):
-            dx.addmm_(da[d].view(L * B, 4 * H), w_ih[d].detach())
+            dx.addmm_(da[d].view(L * B, 4 * H), gate_perm(w_ih[d].detach()))
         ctx.save_for_backward(gates, c_all, lengths, da, dct, dht, *w)
         ctx.dims = (L, B, I, H, nd)
         ctx.has = (dh_all is not None, dh_final is not None)
@@ -285,10 +304,10 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         g_wih, g_whh = [], []
         for d in range(nd):
             da2 = da[d].view(L * B, 4 * H)
-            g_wih.append(wgrad(da2, xh2)[0])
+            g_wih.append(wgrad_gates(da2, xh2)[0])
             hv = hhat_all.view(L * B, nd * H)[:, d * H:(d + 1) * H]
             if L > 1:
-                g_whh.append(wgrad(da2[B:], hv[:-B])[0] if d == 0 else wgrad(da2[:-B], hv[B:])[0])
+                g_whh.append(wgrad_gates(da2[B:], hv[:-B])[0] if d == 0 else wgrad_gates(da2[:-B], hv[B:])[0])
             else:
                 g_whh.append(torch.zeros_like(w_hh[d]))
         return (hhat_all if ctx.has[0] else None, hhat_final if ctx.has[1] else None, g_gates, g_c, None, None,
@@ -346,9 +365,9 @@ class LSTMLayerGPFn(torch.autograd.Function):
                 L, B, H, nd, L_.stream(), label='lstm_bwd_gp2')
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(da[0].view(L * B, 4 * H), w_ih[0])
+            dx = torch.mm(da[0].view(L * B, 4 * H), gate_perm(w_ih[0].detach()))
             for d in range(1, nd):
-                dx.addmm_(da[d].view(L * B, 4 * H), w_ih[d])
+                dx.addmm_(da[d].view(L * B, 4 * H), gate_perm(w_ih[d].detach()))
             dx = dx.view(L, B, I)
         grads = _lstm_weight_grads(da, x.view(L * B, I), h_all, w_hh, L, B, H, nd)
         return (dx, None, *grads)
@@ -472,11 +491,11 @@ class GenRolloutFn(torch.autograd.Function):
         da0 = gates0.view(T * B, 4 * H)
         da1 = gates1.view(T * B, 4 * H)
         h0v, h1v = h0.view(T * B, H), h1.view(T * B, H)
-        d_g0 = gates0.sum(0)                                            # time-invariant input: sum over t
-        d_w_u = wgrad(da0, u.view(T * B, 8))[0][:, :7]
-        d_w_hh0 = wgrad(da0[B:], h0v[:-B])[0] if T > 1 else torch.zeros_like(w_hh0)
-        d_w_ih1, d_bias1 = wgrad(da1, h0d.view(T * B, H), want_db=True)
-        d_w_hh1 = wgrad(da1[B:], h1v[:-B])[0] if T > 1 else torch.zeros_like(w_hh1)
+        d_g0 = gates0.sum(0).view(B, H, 4).transpose(1, 2).reshape(B, 4 * H)   # time-invariant input: sum over t (back to gate-major)
+        d_w_u = wgrad_gates(da0, u.view(T * B, 8))[0][:, :7]
+        d_w_hh0 = wgrad_gates(da0[B:], h0v[:-B])[0] if T > 1 else torch.zeros_like(w_hh0)
+        d_w_ih1, d_bias1 = wgrad_gates(da1, h0d.view(T * B, H), want_db=True)
+        d_w_hh1 = wgrad_gates(da1[B:], h1v[:-B])[0] if T > 1 else torch.zeros_like(w_hh1)
         dyp = d_ypre.view(T * B, HH)
         d_w1, d_b1 = wgrad(dyp, h1v, want_db=True)
         dov = d_o.view(T * B, 3)

@@ -91,11 +91,16 @@ int gmt_pack_weight(const float* src, float* dst, int K, int k_valid, int n_vali
  * length-masked) LSTM.  Replaces the torch.nn.LSTM call at RG.py:772 (construction
  * RG.py:720-727; gate order i,f,g,o).  H in {32, 64, 128, 256}.
  *   x        [L][B][I]   layer input (fused input contraction), or NULL with
- *   pregates [ndir][L][B][4H] = x W_ih^T + b_ih + b_hh precomputed by the caller
+ *   pregates [ndir][L][B][4H] = x W_ih^T + b_ih + b_hh precomputed by the caller, in the
+ *            unit-major column order of the gate buffers (below)
  *   w_ih_pk  [ndir] packed (K = I,  n_gates 4, gate_stride H, stride_k 1, stride_n I)
  *   w_hh_pk  [ndir] packed (K = H,  same form)
  *   bias     [ndir][4H]  b_ih + b_hh (only read with x)
  *   lengths  [B] int32 or NULL (= L); clamped to [1, L] as RG.py:766 does
+ * Gate buffers (gates, d(pre-activation), dgates_extra, g_gates; gates0/1 of the rollout) are
+ * row-major [..][B][4H] with UNIT-MAJOR columns: (unit u, gate g in i,f,g,o) at 4*u + g, so
+ * that a lane moves its four gate values as one float4.  A GEMM that meets such a buffer
+ * uses the weight with its 4H axis permuted the same way (row 4*u+g <- torch row g*H+u).
  * outputs (each may be NULL): gates [ndir][L][B][4H] activated i,f,g,o (may alias
  * pregates), c_all [ndir][L][B][H], h_all [L][B][ndir*H] (zero at padded steps),
  * h_final [B][ndir*H] (forward: state at len-1; reverse: state after t = 0, RG.py:776-778). */

@@ -5,8 +5,16 @@
 #include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+__global__ void fill_rand(float* p, size_t n, float scale, unsigned seed)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = scale * ((float)(gmt_hash32((unsigned)i + seed) >> 8) * (1.0f / 8388608.0f) - 1.0f);
+}
+
 int main(int argc, char** argv)
 {
+    const bool rnd = argc > 1;   // any argument: random data instead of zeros (clock under real switching activity)
+
     const int L = 129, B = 4096, H = 128, ndir = 2;
     for (int IX = 1; IX <= 2; ++IX) {
         const int I = IX * H;
@@ -19,8 +27,15 @@ int main(int argc, char** argv)
         CK(hipMalloc(&c, (size_t)ndir * L * B * H * 4));
         CK(hipMalloc(&h, (size_t)L * B * ndir * H * 4));
         CK(hipMalloc(&hf, (size_t)B * ndir * H * 4));
+        if (rnd) {
+            fill_rand<<<2048, 256>>>(x, (size_t)L * B * I, 0.5f, 1u);
+            fill_rand<<<256, 256>>>(wih, (size_t)ndir * 4 * H * I, 0.09f, 2u);
+            fill_rand<<<256, 256>>>(whh, (size_t)ndir * 4 * H * H, 0.09f, 3u);
+            fill_rand<<<8, 256>>>(bias, (size_t)ndir * 4 * H, 0.09f, 4u);
+            CK(hipDeviceSynchronize());
+        }
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int rep = 0; rep < 3; ++rep) {
+        for (int rep = 0; rep < 6; ++rep) {
             CK(hipEventRecord(e0));
             int rc = gmt_lstm_layer_fwd(x, nullptr, wih, whh, bias, nullptr, gates, c, h, hf, L, B, I, H, ndir, 0);
             CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
