@@ -254,7 +254,8 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
 // resident in registers (or streamed).
 // PLAIN: the ordinary training call (no extra adjoints, no extra outputs, d(pre-activation) in place):
 // no per-row pointer tests in the element-wise phase.
-template <int NW, bool RES, bool PLAIN>
+// HAS_DY: dh_all is given (every layer but the top one, whose only adjoint is dh_final).
+template <int NW, bool RES, bool PLAIN, bool HAS_DY>
 __global__ __launch_bounds__(NW * 64, 1)
 void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, const float* __restrict__ c_all,
                      const float* __restrict__ w_hh_pkT, const int* __restrict__ lengths,
@@ -319,6 +320,11 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
     // their issue slots nor their HBM latency are exposed.  c_t is carried from the previous
     // step's c_prev fetch.
     float pg[4][16], pcp[16], pdy[16], cn_c[16];
+    // addresses = one uniform base per step (scalar registers) + a per-lane 32-bit offset that never changes +
+    // a compile-time row offset: no 64-bit vector arithmetic between the MFMAs
+    const unsigned lo_g = (unsigned)(4 * hi) * (4 * H) + 4 * col;
+    const unsigned lo_c = (unsigned)(4 * hi) * H + col;
+    const unsigned lo_y = (unsigned)(4 * hi) * (ndir * H) + dir * H + col;
     auto prefetch_row = [&](int t, int r) {
         const int tp = dir ? t + 1 : t - 1;
         const bool tp_ok = (tp >= 0) && (tp < L);
@@ -326,9 +332,11 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
         const int mr = (r & 3) + 8 * (r >> 2);
         const float4 q = gmt_ld4(gates + (rs + mr) * (4 * H) + 4 * col);
         pg[0][r] = q.x; pg[1][r] = q.y; pg[2][r] = q.z; pg[3][r] = q.w;
-        const float cpv = c_all[(((size_t)dir * L + (tp_ok ? tp : t)) * B + lane_row + mr) * H + col];
-        pcp[r] = tp_ok ? cpv : 0.f;
-        pdy[r] = dh_all ? dh_all[((size_t)t * B + lane_row + mr) * (ndir * H) + dir * H + col] : 0.f;
+        // raw (tp outside [0, L): c_t itself, unused - selected away at use; touching a loaded value
+        // here would wait for it on the spot)
+        pcp[r] = c_all[(((size_t)dir * L + (tp_ok ? tp : t)) * B + lane_row + mr) * H + col];
+        if constexpr (HAS_DY) pdy[r] = dh_all[((size_t)t * B + lane_row + mr) * (ndir * H) + dir * H + col];
+        else pdy[r] = 0.f;
     };
     if (tmax > 0) {
         const int t0 = dir ? 0 : tmax - 1;
@@ -355,6 +363,7 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
         f32x16 acc[1];
         // MASKED = some row of the tile is past its length at t, or has no earlier step: selects,
         // no branches; otherwise every row is live and has a predecessor (or tp < 0 for all)
+        const bool tp_in = (tp >= 0) && (tp < L);      // uniform: the forward pass had an earlier step at all
         auto sweep = [&](auto masked) {
             constexpr bool MASKED = decltype(masked)::value;
             unsigned am = 0xffffu, pm = 0xffffu;
@@ -374,7 +383,7 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
                 const bool has_prev = !MASKED || ((pm >> r) & 1u);
                 const float ig = pg[0][r], fg = pg[1][r], gg = pg[2][r], og = pg[3][r];
                 const float cn = cn_c[r];
-                const float cp = has_prev ? pcp[r] : 0.f;
+                const float cp = (has_prev && tp_in) ? pcp[r] : 0.f;
                 const float dht = dh[r] + pdy[r];
                 const float tc = gmt_tanh(cn);
                 float dog = dht * tc;
@@ -481,7 +490,8 @@ int launch_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const in
     const size_t lds = (size_t)(4 * H) * GMT_LDA * sizeof(float) + ((RES && NW == 4) ? (size_t)NW * GMT_BWD_KL * 64 * sizeof(float) : 0);
     if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;
     const bool plain = !dgates_extra && !dc_extra && !da_out && !dct_out && !dht_out;
-    auto k = plain ? lstm_bwd_kernel<NW, RES, true> : lstm_bwd_kernel<NW, RES, false>;
+    auto k = plain ? (dh_all ? lstm_bwd_kernel<NW, RES, true, true> : lstm_bwd_kernel<NW, RES, true, false>)
+                   : (dh_all ? lstm_bwd_kernel<NW, RES, false, true> : lstm_bwd_kernel<NW, RES, false, false>);
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GMT_ERR_HIP;
     hipLaunchKernelGGL(k, dim3(n_tiles * ndir), dim3(NW * 64), lds, stream, gates, c_all, w_hh_pkT, lengths,

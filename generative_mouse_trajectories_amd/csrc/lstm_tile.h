@@ -34,6 +34,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // resident weights need).
 template <class T> __device__ __forceinline__ T* gmt_opaque_v(T* p) { asm volatile("" : "+v"(p)); return p; }
 template <class T> __device__ __forceinline__ T* gmt_opaque_s(T* p) { asm volatile("" : "+s"(p)); return p; }
+// the same for a per-lane offset: keeps `offset + constant` from being hoisted into one live register per constant
+__device__ __forceinline__ unsigned gmt_opaque_u(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 
 // Counter-based dropout mask (inter-layer LSTM dropout, RecurrentGAN.py:456): the keep decision of
 // element `idx` is a pure function of (seed, idx), so forward and backward regenerate the same
