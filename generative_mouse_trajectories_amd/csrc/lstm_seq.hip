@@ -255,7 +255,9 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
 // PLAIN: the ordinary training call (no extra adjoints, no extra outputs, d(pre-activation) in place):
 // no per-row pointer tests in the element-wise phase.
 // HAS_DY: dh_all is given (every layer but the top one, whose only adjoint is dh_final).
-template <int NW, bool RES, bool PLAIN, bool HAS_DY>
+// EXTRA (gradient penalty, second backward): dgates_extra and dc_extra are both given and are prefetched
+// with the other operands; given singly they are read at use.
+template <int NW, bool RES, bool PLAIN, bool HAS_DY, bool EXTRA>
 __global__ __launch_bounds__(NW * 64, 1)
 void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, const float* __restrict__ c_all,
                      const float* __restrict__ w_hh_pkT, const int* __restrict__ lengths,
@@ -320,6 +322,7 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
     // their issue slots nor their HBM latency are exposed.  c_t is carried from the previous
     // step's c_prev fetch.
     float pg[4][16], pcp[16], pdy[16], cn_c[16];
+    float pge[EXTRA ? 4 : 1][16], pce[16];             // EXTRA: adjoints of the saved gates / cells of the next step
     // addresses = one uniform base per step (scalar registers) + a per-lane 32-bit offset that never changes +
     // a compile-time row offset: no 64-bit vector arithmetic between the MFMAs
     const unsigned lo_g = (unsigned)(4 * hi) * (4 * H) + 4 * col;
@@ -337,6 +340,11 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
         pcp[r] = c_all[(((size_t)dir * L + (tp_ok ? tp : t)) * B + lane_row + mr) * H + col];
         if constexpr (HAS_DY) pdy[r] = dh_all[((size_t)t * B + lane_row + mr) * (ndir * H) + dir * H + col];
         else pdy[r] = 0.f;
+        if constexpr (EXTRA) {
+            const float4 e = gmt_ld4(dgates_extra + (rs + mr) * (4 * H) + 4 * col);
+            pge[0][r] = e.x; pge[1][r] = e.y; pge[2][r] = e.z; pge[3][r] = e.w;
+            pce[r] = dc_extra[(rs + mr) * H + col];
+        }
     };
     if (tmax > 0) {
         const int t0 = dir ? 0 : tmax - 1;
@@ -388,9 +396,12 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
                 const float tc = gmt_tanh(cn);
                 float dog = dht * tc;
                 float dct = dc[r] + dht * og * (1.f - tc * tc);
-                if (!PLAIN && ce_p) dct += ce_p[(size_t)mr * H];
+                if constexpr (EXTRA) dct += pce[r];
+                else if (!PLAIN && ce_p) dct += ce_p[(size_t)mr * H];
                 float dig = dct * gg, dgg = dct * ig, dfg = dct * cp;
-                if (!PLAIN && ge_p) {
+                if constexpr (EXTRA) {
+                    dig += pge[0][r]; dfg += pge[1][r]; dgg += pge[2][r]; dog += pge[3][r];
+                } else if (!PLAIN && ge_p) {
                     const float4 ep = gmt_ld4(ge_p + (size_t)mr * (4 * H));
                     dig += ep.x; dfg += ep.y; dgg += ep.z; dog += ep.w;
                 }
@@ -490,8 +501,10 @@ int launch_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const in
     const size_t lds = (size_t)(4 * H) * GMT_LDA * sizeof(float) + ((RES && NW == 4) ? (size_t)NW * GMT_BWD_KL * 64 * sizeof(float) : 0);
     if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;
     const bool plain = !dgates_extra && !dc_extra && !da_out && !dct_out && !dht_out;
-    auto k = plain ? (dh_all ? lstm_bwd_kernel<NW, RES, true, true> : lstm_bwd_kernel<NW, RES, true, false>)
-                   : (dh_all ? lstm_bwd_kernel<NW, RES, false, true> : lstm_bwd_kernel<NW, RES, false, false>);
+    const bool extra = dgates_extra && dc_extra;
+    auto k = plain ? (dh_all ? lstm_bwd_kernel<NW, RES, true, true, false> : lstm_bwd_kernel<NW, RES, true, false, false>)
+           : extra ? (dh_all ? lstm_bwd_kernel<NW, RES, false, true, true> : lstm_bwd_kernel<NW, RES, false, false, true>)
+                   : (dh_all ? lstm_bwd_kernel<NW, RES, false, true, false> : lstm_bwd_kernel<NW, RES, false, false, false>);
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GMT_ERR_HIP;
     hipLaunchKernelGGL(k, dim3(n_tiles * ndir), dim3(NW * 64), lds, stream, gates, c_all, w_hh_pkT, lengths,
