@@ -180,33 +180,8 @@ __device__ __forceinline__ void gmt_mma_stream(f32x16 (&acc)[NG], const float* _
     }
 }
 
-// gmt_mma_stream for a compile-time K, fully unrolled, with the side hook of gmt_mma_resident:
-// side(i) is called K/8 times (i = k-group index), each ahead of 4*NG MFMAs.
-template <int NG, int K, class Side>
-__device__ __forceinline__ void gmt_mma_stream_static(f32x16 (&acc)[NG], const float* __restrict__ lds_a,
-                                                      const float4* __restrict__ wpk, int lane, Side side)
-{
-    constexpr int ns4 = K / 8;
-    static_assert(ns4 % 2 == 0, "K must be a multiple of 16");
-    const int hi = lane >> 5, lo = lane & 31;
-    const float* ap = lds_a + hi * GMT_LDA + lo;
-    float4 w0[NG], w1[NG];
-    float a0[4], a1[4];
-    gmt_stream_fetch<NG>(w0, a0, wpk, ap, 0, lane);
-#pragma unroll
-    for (int s4 = 0; s4 < ns4; s4 += 2) {
-        gmt_stream_fetch<NG>(w1, a1, wpk, ap, s4 + 1, lane);
-        side(s4);
-        __builtin_amdgcn_sched_barrier(0);
-        gmt_mma_group<NG>(acc, a0, w0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s4 + 2 < ns4) gmt_stream_fetch<NG>(w0, a0, wpk, ap, s4 + 2, lane);   // static after unrolling
-        side(s4 + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        gmt_mma_group<NG>(acc, a1, w1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
+// (A fully unrolled variant of gmt_mma_stream with a per-stage hook was tried for interleaving prefetch loads
+// with the streamed MFMAs: the register allocator then keeps every stage's operands apart and spills > 1 KB a lane.)
 
 // Same contraction with the weights already on chip: wr[g][s], s = k-step, holds the first KR
 // k-steps in registers; the remaining KS - KR k-steps (NG == 4 only) sit in LDS in the packed fragment
