@@ -51,7 +51,7 @@ def synthetic_batch(B, T, seed, device):
     return {k: v.to(device) for k, v in b.items()}
 
 
-def cpu_baseline(threads: int, B: int = 128):
+def cpu_baseline(threads: int, B: int = 256):
     """The CPU oracle (oracle/gan_oracle.py, pinned to the reference by tests/golden) timed on
     this host, SURVEY.md section 8d: same synthetic batch at a reduced B, dropout on, one warm-up
     iteration, then 4 iterations (D steps 0..3: the first carries the gradient penalty) so the GP
