@@ -34,6 +34,10 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
     extern __shared__ float smem[];
     float* hT = smem;                                  // [2][H][LDA]  hhat state
     float* xT = smem + 2 * H * GMT_LDA;                // [2][I][LDA]
+    // at H = 128 the last KL k-steps of W_hh live in LDS, not registers (as in lstm_fwd_kernel)
+    constexpr int KL = (RES && NW == 4) ? (IX == 1 ? 16 : 8) : 0;
+    constexpr int KR = KS - KL;
+    float4* wl = reinterpret_cast<float4*>(smem + (2 * H + 2 * I) * GMT_LDA) + (size_t)(threadIdx.x >> 6) * (KL / 4) * 4 * 64;
     __shared__ int s_len[GMT_TM];
     __shared__ int s_maxlen;
 
@@ -58,12 +62,16 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
 
     const float4* whh = reinterpret_cast<const float4*>(w_hh_pk) + ((size_t)dir * NW + wave) * (H / 8) * 4 * 64;
     const float4* wih = reinterpret_cast<const float4*>(w_ih_pk) + ((size_t)dir * NW + wave) * (I / 8) * 4 * 64;
-    float wr[4][RES ? KS : 1];
-    if constexpr (RES) gmt_load_resident<4, KS>(wr, whh, lane);
+    float wr[4][RES ? KR : 1];
+    if constexpr (RES) {
+        gmt_load_resident<4, KR>(wr, whh, lane);
+        for (int i = lane; i < (KL / 4) * 4 * 64; i += 64) wl[i] = whh[(KR / 4) * 4 * 64 + i];   // visible after the next barrier
+    }
 
     float chat[16];                                    // adjoint of the incoming cell adjoint (carried)
+    float gc_pend[16];                                 // g_c of the step before, still missing this step's term
 #pragma unroll
-    for (int r = 0; r < 16; ++r) chat[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { chat[r] = 0.f; gc_pend[r] = 0.f; }
 
     constexpr int XQ = I / 4;
     constexpr int XS = (GMT_TM * XQ) / NT;
@@ -100,7 +108,7 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
         gmt_mma_stream<4>(acc, xT + (size_t)cur * I * GMT_LDA, wih, I, lane);
-        if constexpr (RES) gmt_mma_resident<4, KS>(acc, hT + (size_t)cur * H * GMT_LDA, wr, lane);
+        if constexpr (RES) gmt_mma_resident<4, KS, KR>(acc, hT + (size_t)cur * H * GMT_LDA, wr, lane, wl);
         else gmt_mma_stream<4>(acc, hT + (size_t)cur * H * GMT_LDA, whh, H, lane);
 
         const float* ho = hT + (size_t)cur * H * GMT_LDA + col * GMT_LDA + 4 * hi;
@@ -111,23 +119,37 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
         const float* dct_p = dct_all + rs * H + col;
         const float* dht_p = dht_all + rs * H + col;
         float* gg_p = g_gates + rs * (4 * H) + 4 * col;
-        float* gc_p = g_c + rs * H + col;
         float* gcp_p = g_c + rsp * H + col;
         float* hh_p = hhat_all ? hhat_all + ((size_t)t * B + lane_row) * (ndir * H) + dir * H + col : nullptr;
+        const bool tp_in = (tp >= 0) && (tp < L);
+        constexpr int RB = (NW >= 4) ? 4 : 8;          // rows per batch (register budget at H >= 128)
+        // RB rows at a time: all their operands are requested before the first is used (one HBM round trip
+        // per batch instead of one per row), and the row math is selects, not branches.  g_c of a step also
+        // receives a term from the step after it (c_{t} enters f-gate adjoint of t+1): it is kept in
+        // registers for one step (gc_pend) and stored then, instead of a read-modify-write.
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mr = (r & 3) + 8 * (r >> 2);
-            const int ln = s_len[mr + 4 * hi];
-            const bool act = t < ln;
-            float o_gi = 0.f, o_gf = 0.f, o_gg = 0.f, o_go = 0.f, o_gc = 0.f, o_hh = 0.f;
-            float hnew = ho[mr];
-            if (act) {
-                const float4 q = gmt_ld4(gp + (size_t)mr * (4 * H));
-                const float ig = q.x, fg = q.y, gg = q.z, og = q.w;
-                const float cn = cn_p[(size_t)mr * H];
-                const bool has_prev = dir ? (tp < ln) : (tp >= 0);
-                const float cp = has_prev ? cp_p[(size_t)mr * H] : 0.f;
-                const float dct = dct_p[(size_t)mr * H], dht = dht_p[(size_t)mr * H];
+        for (int half = 0; half < 16 / RB; ++half) {
+            float4 q4[RB];
+            float v_cn[RB], v_cp[RB], v_dct[RB], v_dht[RB];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int r = half * RB + j, mr = (r & 3) + 8 * (r >> 2);
+                q4[j] = gmt_ld4(gp + (size_t)mr * (4 * H));
+                v_cn[j] = cn_p[(size_t)mr * H];
+                v_cp[j] = cp_p[(size_t)mr * H];
+                v_dct[j] = dct_p[(size_t)mr * H];
+                v_dht[j] = dht_p[(size_t)mr * H];
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int r = half * RB + j, mr = (r & 3) + 8 * (r >> 2);
+                const int ln = s_len[mr + 4 * hi];
+                const bool act = t < ln;
+                const bool has_prev = tp_in && (dir ? (tp < ln) : true);
+                const float ig = q4[j].x, fg = q4[j].y, gg = q4[j].z, og = q4[j].w;
+                const float cn = v_cn[j];
+                const float cp = has_prev ? v_cp[j] : 0.f;
+                const float dct = v_dct[j], dht = v_dht[j];
                 const float tc = gmt_tanh(cn);
                 const float omt = 1.f - tc * tc;
                 // intermediates of the first backward sweep
@@ -139,21 +161,27 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
                 const float ado = a_o * og * (1.f - og);
                 const float cprev_hat = chat[r];
                 const float adct = adi * gg + adg * ig + adf * cp + cprev_hat * fg;
-                o_gi = a_i * di * (1.f - 2.f * ig) + adg * dct;
-                o_gf = a_f * df * (1.f - 2.f * fg) + cprev_hat * dct;
-                o_gg = a_g * dg * (-2.f * gg) + adi * dct;
-                o_go = a_o * dov * (1.f - 2.f * og) + adct * dht * omt;
+                const float o_gi = a_i * di * (1.f - 2.f * ig) + adg * dct;
+                const float o_gf = a_f * df * (1.f - 2.f * fg) + cprev_hat * dct;
+                const float o_gg = a_g * dg * (-2.f * gg) + adi * dct;
+                const float o_go = a_o * dov * (1.f - 2.f * og) + adct * dht * omt;
                 const float atc = adct * dht * og * (-2.f * tc) + ado * dht;
-                o_gc = atc * omt;
-                chat[r] = adct;
-                hnew = adct * og * omt + ado * tc;
-                o_hh = hnew;
-                if (has_prev) gcp_p[(size_t)mr * H] += adf * dct;      // c_{prev} also enters df of this step
+                const float o_gc = atc * omt;
+                const float hnew = adct * og * omt + ado * tc;
+                chat[r] = act ? adct : chat[r];
+                hn[mr] = act ? hnew : ho[mr];
+                gmt_st4(gg_p + (size_t)mr * (4 * H), act ? o_gi : 0.f, act ? o_gf : 0.f, act ? o_gg : 0.f, act ? o_go : 0.f);
+                // the step before this one (if the sweep had one) now has its complete g_c
+                if (step > 0) gcp_p[(size_t)mr * H] = gc_pend[r] + ((act && has_prev) ? adf * dct : 0.f);
+                gc_pend[r] = act ? o_gc : 0.f;
+                if (hh_p) hh_p[(size_t)mr * (ndir * H)] = act ? hnew : 0.f;
             }
-            hn[mr] = hnew;
-            gmt_st4(gg_p + (size_t)mr * (4 * H), o_gi, o_gf, o_gg, o_go);
-            gc_p[(size_t)mr * H] = o_gc;
-            if (hh_p) hh_p[(size_t)mr * (ndir * H)] = o_hh;
+            __builtin_amdgcn_sched_barrier(0);         // keep the next batch's loads from being hoisted up here
+        }
+        if (step + 1 == tmax) {                        // the last step of the sweep has no successor
+            float* gc_p = g_c + rs * H + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gc_p[(size_t)((r & 3) + 8 * (r >> 2)) * H] = gc_pend[r];
         }
         if (step + 1 < tmax) x_store(cur ^ 1);
         __syncthreads();
@@ -192,7 +220,8 @@ int launch_bwd2(const float* xhat, const float* w_ih_pk, const float* w_hh_pk, c
     const dim3 grid(n_tiles * ndir), block(NW * 64);
 #define GMT_GO(IXV)                                                                                               \
     {                                                                                                             \
-        const size_t lds = (size_t)(2 * H + 2 * IXV * H) * GMT_LDA * sizeof(float);                               \
+        const size_t lds = (size_t)(2 * H + 2 * IXV * H) * GMT_LDA * sizeof(float)                                \
+                           + ((RES && NW == 4) ? (size_t)NW * (IXV == 1 ? 16 : 8) * 4 * 64 * sizeof(float) : 0);  \
         if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;                                                   \
         auto k = lstm_bwd2_kernel<NW, RES, IXV>;                                                                  \
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
