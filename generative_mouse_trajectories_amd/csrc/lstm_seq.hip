@@ -8,9 +8,10 @@
 // only when t < len; the reverse direction walks t = L-1 .. 0 and therefore starts each
 // row at its own last valid step with zero state.  Outputs at padded steps are zero.
 //
-// Forward saves the activated gates (i,f,g,o), c and h of every step for the backward
-// sweep; backward overwrites the gate buffer in place with d(pre-activation), which the
-// host then contracts with x / h_prev for the weight gradients (one large GEMM each).
+// Forward saves the activated gates (i,f,g,o; unit-major columns, see lstm_tile.h), c and h of
+// every step for the backward sweep; backward overwrites the gate buffer in place with
+// d(pre-activation), which the host then contracts with x / h_prev for the weight gradients
+// (csrc/wgrad.hip) and with W_ih for the input gradient.
 #include "lstm_tile.h"
 #include <type_traits>
 
@@ -48,6 +49,7 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
 // NW waves (H = 32 NW).  RES: recurrent weights resident in registers.  IX = I / H:
 //   IX = 0  the caller precomputed x W_ih^T + b into `pregates` (read from HBM);
 //   IX = 1,2 the input contraction runs inside the kernel, W_ih streamed from L2.
+// FULL: gates, c_all and h_all are all given (the training call): stores without pointer tests.
 // B must be a multiple of 32 (the host pads the batch), so there are no row guards.
 template <int NW, bool RES, int IX, bool FULL>
 __global__ __launch_bounds__(NW * 64, 1)
