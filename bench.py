@@ -92,7 +92,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--batch', type=int, default=B_LOCAL)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='run the two generator rollouts of an iteration one after the other')
