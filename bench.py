@@ -199,6 +199,7 @@ def main():
             'step_tflops': value * f_iter / 1e12,
             'frac_of_f32_mfma_peak': value * f_iter / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
             'roofline': roof,
+            'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated() / 1e9,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
