@@ -85,3 +85,26 @@ def test_gradients_are_additive_over_the_batch_at_full_size():
         # two associations of an fp32 sum over 5.3e5 row-steps whose terms largely cancel: 5e-4, not the 1e-4 of
         # the parity tests against the oracle
         H.assert_close(ga + gb, gt, 5e-4, f'dL/d(param of shape {tuple(p.shape)}): halves vs full batch')
+
+
+def test_telemetry_recompute_at_sampling_scale():
+    """Config 5's metric recompute: 65 536 trajectories x 256 points in one launch; 24 of them (first, last and a
+    stride through the middle, ragged lengths) against the C oracle, to the bit-exactness bar of the small test."""
+    from oracle import telemetry as TO
+    from generative_mouse_trajectories_amd import telemetry as TEL
+    n, n_max = 65536, 256
+    g = torch.Generator().manual_seed(9)
+    x = torch.cumsum(torch.randn(n_max, n, generator=g, dtype=torch.float64) * 3.0, 0) + 500.0
+    y = torch.cumsum(torch.randn(n_max, n, generator=g, dtype=torch.float64) * 3.0, 0) + 400.0
+    dt = torch.rand(n_max, n, generator=g, dtype=torch.float64) * 0.02 + 0.001      # some below MIN_DERIVATIVE_DT
+    lens = torch.randint(2, n_max + 1, (n,), generator=g, dtype=torch.int32)
+    lens[0] = n_max; lens[-1] = 2
+    kin = TEL.telemetry_kinematics(x.to(DEV), y.to(DEV), dt.to(DEV), lens.to(DEV), time_is_dt=True).cpu().numpy()
+    for r in [0, n - 1] + list(range(1000, n, n // 22)):
+        m = int(lens[r])
+        o = TO.kinematics(x[:m, r].numpy().copy(), y[:m, r].numpy().copy(), dt[:m, r].numpy().copy(), True)
+        for j, k in enumerate(('velocity', 'acceleration', 'jerk', 'path_length', 'direction')):
+            ref = o[k]
+            assert np.abs(kin[j, :m, r] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1.0), (k, r)
+        ref = o['curvature']
+        assert np.abs(kin[5, :m, r] - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-300), ('curvature', r)
