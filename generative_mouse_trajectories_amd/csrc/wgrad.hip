@@ -11,6 +11,7 @@
 //     order (deterministic; float atomics would make gradients run-to-run different);
 //   * the column sums of dA (= bias gradient) are accumulated by the staging threads for free.
 #include "lstm_tile.h"
+#include <cstdlib>
 
 namespace {
 
@@ -253,7 +254,8 @@ extern "C" int gmt_wgrad_workspace_floats(int N, int I, long long R, int* ksplit
     GMT_CHECK_ARG(shape >= 0 && R >= WG_RC && (R % WG_RC) == 0);
     const int TN = (shape == 0 || shape == 2) ? 256 : 128, TI = (shape <= 1) ? 128 : 32;
     const int tiles = ((N + TN - 1) / TN) * ((I + TI - 1) / TI);
-    int ks = (2 * 256 + tiles - 1) / tiles;             // ~2 workgroups per CU
+    static const int per_cu = [] { const char* e = getenv("GMT_WGRAD_WG_PER_CU"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    int ks = (per_cu * 256 + tiles - 1) / tiles;        // ~2 workgroups per CU (tuning knob: GMT_WGRAD_WG_PER_CU)
     const long long n_chunks = R / WG_RC;
     if (ks > n_chunks) ks = (int)n_chunks;
     if (ks < 1) ks = 1;
