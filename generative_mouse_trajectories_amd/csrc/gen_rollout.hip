@@ -91,11 +91,12 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
     int cur = 0;
     f32x16 acc0[4];
     auto g0_load = [&]() {
-        const float* gp = gmt_opaque_v(a.g0 + lane_row * (4 * H) + col);
+        const float* gp = gmt_opaque_v(a.g0 + lane_row * (4 * H) + 4 * col);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[g][r] = gp[(size_t)((r & 3) + 8 * (r >> 2)) * (4 * H) + g * H];
+        for (int r = 0; r < 16; ++r) {
+            const float4 v = gmt_ld4(gp + (size_t)((r & 3) + 8 * (r >> 2)) * (4 * H));
+            acc0[0][r] = v.x; acc0[1][r] = v.y; acc0[2][r] = v.z; acc0[3][r] = v.w;
+        }
     };
     g0_load();
     __syncthreads();

@@ -139,6 +139,8 @@ class Generator(nn.Module):
         w_u = torch.cat([w_ih0[:, :3], w_ih0[:, 3 + H:]], dim=1)
         bias1 = lp.bias_ih_l1 + lp.bias_hh_l1
         g0 = _pad_batch(g0, Bp, 0)
+        # the rollout kernel reads it in the unit-major column order of its gate buffers (one float4 per row and unit)
+        g0 = g0.view(Bp, 4, H).transpose(1, 2).reshape(Bp, 4 * H)
         s_p, e_p = _pad_batch(start, Bp, 0), _pad_batch(end, Bp, 0)
         if target_tm is not None:
             target_tm = _pad_batch(target_tm, Bp, 1).contiguous()

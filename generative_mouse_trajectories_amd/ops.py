@@ -399,7 +399,7 @@ def _pack1(w: torch.Tensor, K: int, k_valid: int, n_valid: int, n_waves: int, n_
 
 class GenRolloutFn(torch.autograd.Function):
     """Inputs (all fp32, cuda):
-      g0 [B,4H], w_u [4H,7], w_hh0 [4H,H], w_ih1 [4H,H], w_hh1 [4H,H], bias1 [4H],
+      g0 [B,4H] (unit-major columns 4*unit + gate), w_u [4H,7], w_hh0 [4H,H], w_ih1 [4H,H], w_hh1 [4H,H], bias1 [4H],
       w1 [H/2,H], b1 [H/2], w2 [3,H/2], b2 [3], init_in [3], starts [B,2], ends [B,2],
       target [T,B,3] or None, tf_mask uint8 [T] (device) or None, T.
     Output: out_seq [T,B,3].  B % 32 == 0."""
@@ -491,7 +491,7 @@ class GenRolloutFn(torch.autograd.Function):
         da0 = gates0.view(T * B, 4 * H)
         da1 = gates1.view(T * B, 4 * H)
         h0v, h1v = h0.view(T * B, H), h1.view(T * B, H)
-        d_g0 = gates0.sum(0).view(B, H, 4).transpose(1, 2).reshape(B, 4 * H)   # time-invariant input: sum over t (back to gate-major)
+        d_g0 = gates0.sum(0)                                            # time-invariant input: sum over t (unit-major, like g0)
         d_w_u = wgrad_gates(da0, u.view(T * B, 8))[0][:, :7]
         d_w_hh0 = wgrad_gates(da0[B:], h0v[:-B])[0] if T > 1 else torch.zeros_like(w_hh0)
         d_w_ih1, d_bias1 = wgrad_gates(da1, h0d.view(T * B, H), want_db=True)

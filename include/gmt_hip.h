@@ -152,7 +152,7 @@ int gmt_wgrad(const float* dA, long long lda, const float* X, long long ldx, lon
  * All buffers time-major; B % 32 == 0; H in {32, 64, 128, 256}; HH = H/2.  Packed operands
  * are produced by gmt_pack_weight (form given per field). */
 typedef struct gmt_gen_fwd_args {
-    const float* g0;        /* [B][4H]  condition . W_ih_l0[:, 3:3+H]^T + b_ih_l0 + b_hh_l0 (time-invariant) */
+    const float* g0;        /* [B][4H]  condition . W_ih_l0[:, 3:3+H]^T + b_ih_l0 + b_hh_l0 (time-invariant), unit-major columns */
     const float* w_u_pk;    /* W_u = W_ih_l0[:, {0,1,2, 3+H..3+H+3}] ([4H][7]); K 8, k_valid 7, 4 gates, stride_n 7 */
     const float* w_hh0_pk;  /* K H, 4 gates */
     const float* w_ih1_pk;  /* K H, 4 gates */
