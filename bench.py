@@ -89,6 +89,9 @@ def cpu_baseline(threads: int, B: int = 256):
 
 
 def main():
+    if os.environ.get('GMT_DEBUG_HANG'):              # diagnosis aid: dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['GMT_DEBUG_HANG']), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
@@ -102,13 +105,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank %= max(1, torch.cuda.device_count())       # (rehearsing N ranks on a one-GPU box: they share the card)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     pg = None
     force_dist = bool(os.environ.get('GMT_FORCE_DIST'))      # exercise the RCCL path with one rank
     if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('GMT_DIST_BACKEND', 'nccl')   # 'gloo' to rehearse the multi-rank path on one GPU
+        dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
         pg = dist.group.WORLD
 
     import generative_mouse_trajectories_amd as gmt
