@@ -46,11 +46,11 @@ _SIGS = {
     'gmt_telemetry_derived_f64': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_p],
     'gmt_adam_step': [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_f, c_p],
     'gmt_pack_weight': [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_p],
-    'gmt_lstm_layer_fwd': [c_p] * 10 + [c_i] * 5 + [c_p],
-    'gmt_lstm_layer_bwd': [c_p] * 11 + [c_i] * 4 + [c_p],
+    'gmt_lstm_layer_fwd': [c_p] * 10 + [c_i] * 5 + [c_f, ctypes.c_uint, c_p],
+    'gmt_lstm_layer_bwd': [c_p] * 11 + [c_i] * 4 + [c_f, ctypes.c_uint, c_p],
     'gmt_lstm_layer_bwd2': [c_p] * 12 + [c_i] * 5 + [c_p],
     'gmt_wgrad_workspace_floats': [c_i, c_i, c_ll, c_p, c_p],
-    'gmt_wgrad': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_ll, c_p],
+    'gmt_wgrad': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_ll, c_f, ctypes.c_uint, c_p],
     'gmt_gen_rollout_fwd': [c_p, c_p],
     'gmt_gen_rollout_bwd': [c_p, c_p],
 }

@@ -57,11 +57,16 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
                      const float* __restrict__ w_ih_pk, const float* __restrict__ w_hh_pk,
                      const float* __restrict__ bias, const int* __restrict__ lengths,
                      float* __restrict__ gates, float* __restrict__ c_all, float* __restrict__ h_all,
-                     float* __restrict__ h_final, int L, int B, int ndir, int n_tiles)
+                     float* __restrict__ h_final, int L, int B, int ndir, int n_tiles,
+                     float x_drop_p, uint32_t x_drop_seed)
 {
     constexpr int H = NW * 32;
     constexpr int KS = H / 2;
     constexpr int I = (IX > 0 ? IX : 1) * H;
+    // inverted dropout on the layer input (the inter-layer dropout of nn.LSTM, RG.py:640): element
+    // (t, row, k) of x is kept iff gmt_keep16((t*B + row)*I + k, seed)
+    const uint32_t x_thresh16 = (uint32_t)(x_drop_p * 65536.0f);
+    const float x_keep_scale = 1.0f / (1.0f - x_drop_p);
     constexpr int NT = NW * 64;
     extern __shared__ float smem[];
     // at H = 128 with the fused input contraction the last KL k-steps of W_hh live in LDS, not registers
@@ -131,11 +136,16 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
 #pragma unroll
         for (int j = 0; j < XS; ++j) xs[j] = (src + j * NT)[tid];   // uniform base + one lane offset
     };
-    auto x_store = [&]() {
+    auto x_store = [&](int t) {
         // item tid + j*NT is row tid/XQ + j*(NT/XQ), float4 column tid%XQ: one LDS address, the
         // j-th float4 sits j*(NT/XQ) floats further on
         static_assert(NT % XQ == 0, "x tile staging assumes NT is a multiple of I/4");
         float* d0 = xT + (size_t)(4 * (tid % XQ)) * GMT_LDA + tid / XQ;
+        if (x_thresh16) {                              // uniform: the dropped copy of x exists only in LDS
+            const uint32_t i0 = (uint32_t)(((size_t)t * B + row0) * I) + 4u * (uint32_t)tid;
+#pragma unroll
+            for (int j = 0; j < XS; ++j) gmt_drop4(xs[j], i0 + (uint32_t)(j * NT * 4), x_drop_seed, x_thresh16, x_keep_scale);
+        }
 #pragma unroll
         for (int j = 0; j < XS; ++j) {
             float* d = d0 + j * (NT / XQ);
@@ -171,7 +181,7 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
         if constexpr (RES) gmt_mma_resident<4, KS, KR>(acc, hT, wr, lane, wl);
         else gmt_mma_stream<4>(acc, hT, whh, H, lane);
         GMT_PH(1);
-        if constexpr (IX > 0) x_store();
+        if constexpr (IX > 0) x_store(t);
         GMT_PH(3);
         __syncthreads();                               // B
         GMT_PH(4);
@@ -256,10 +266,11 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
 // resident in registers (or streamed).
 // PLAIN: the ordinary training call (no extra adjoints, no extra outputs, d(pre-activation) in place):
 // no per-row pointer tests in the element-wise phase.
-// HAS_DY: dh_all is given (every layer but the top one, whose only adjoint is dh_final).
+// DY: 0 no dh_all (the top layer, whose only adjoint is dh_final); 1 dh_all is given; 2 dh_all is given and is
+// the adjoint of the DROPPED output (inter-layer dropout fused into the consumer): the keep mask is applied here.
 // EXTRA (gradient penalty, second backward): dgates_extra and dc_extra are both given and are prefetched
 // with the other operands; given singly they are read at use.
-template <int NW, bool RES, bool PLAIN, bool HAS_DY, bool EXTRA>
+template <int NW, bool RES, bool PLAIN, int DY, bool EXTRA>
 __global__ __launch_bounds__(NW * 64, 1)
 void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, const float* __restrict__ c_all,
                      const float* __restrict__ w_hh_pkT, const int* __restrict__ lengths,
@@ -270,10 +281,13 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
                      float* __restrict__ da_out /* null: overwrite `gates` in place */,
                      float* __restrict__ dct_out /* [ndir][L][B][H] or null: total cell adjoint (double backward) */,
                      float* __restrict__ dht_out /* [ndir][L][B][H] or null: total hidden adjoint (double backward) */,
-                     int L, int B, int ndir, int n_tiles)
+                     int L, int B, int ndir, int n_tiles, float dy_drop_p, uint32_t dy_drop_seed)
 {
     constexpr int H = NW * 32;
     constexpr int KS = 2 * H;                          // k-steps over K = 4H
+    constexpr bool HAS_DY = DY > 0;
+    const uint32_t dy_thresh16 = (uint32_t)(dy_drop_p * 65536.0f);
+    const float dy_keep_scale = 1.0f / (1.0f - dy_drop_p);
     // at H = 128 the last KL k-steps of W_hh^T live in LDS, not registers (the prefetch registers need the room)
     constexpr int KL = (RES && NW == 4) ? GMT_BWD_KL : 0;
     constexpr int KR = KS - KL;
@@ -325,11 +339,6 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
     // step's c_prev fetch.
     float pg[4][16], pcp[16], pdy[16], cn_c[16];
     float pge[EXTRA ? 4 : 1][16], pce[16];             // EXTRA: adjoints of the saved gates / cells of the next step
-    // addresses = one uniform base per step (scalar registers) + a per-lane 32-bit offset that never changes +
-    // a compile-time row offset: no 64-bit vector arithmetic between the MFMAs
-    const unsigned lo_g = (unsigned)(4 * hi) * (4 * H) + 4 * col;
-    const unsigned lo_c = (unsigned)(4 * hi) * H + col;
-    const unsigned lo_y = (unsigned)(4 * hi) * (ndir * H) + dir * H + col;
     auto prefetch_row = [&](int t, int r) {
         const int tp = dir ? t + 1 : t - 1;
         const bool tp_ok = (tp >= 0) && (tp < L);
@@ -394,7 +403,11 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
                 const float ig = pg[0][r], fg = pg[1][r], gg = pg[2][r], og = pg[3][r];
                 const float cn = cn_c[r];
                 const float cp = (has_prev && tp_in) ? pcp[r] : 0.f;
-                const float dht = dh[r] + pdy[r];
+                float dht = dh[r] + pdy[r];
+                if constexpr (DY == 2) {               // same element index as the consumer's x staging
+                    const uint32_t i = (uint32_t)(((size_t)t * B + lane_row + mr) * (ndir * H)) + dir * H + col;
+                    dht = dh[r] + (gmt_keep16(i, dy_drop_seed, dy_thresh16) ? pdy[r] * dy_keep_scale : 0.f);
+                }
                 const float tc = gmt_tanh(cn);
                 float dog = dht * tc;
                 float dct = dc[r] + dht * og * (1.f - tc * tc);
@@ -465,7 +478,7 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
 template <int NW>
 int launch_fwd(const float* x, const float* pregates, const float* w_ih_pk, const float* w_hh_pk, const float* bias,
                const int* lengths, float* gates, float* c_all, float* h_all, float* h_final,
-               int L, int B, int I, int ndir, hipStream_t stream)
+               int L, int B, int I, int ndir, float x_drop_p, uint32_t x_drop_seed, hipStream_t stream)
 {
     constexpr int H = NW * 32;
     constexpr bool RES = (NW <= 4);
@@ -481,7 +494,7 @@ int launch_fwd(const float* x, const float* pregates, const float* w_ih_pk, cons
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return GMT_ERR_HIP;                                                                                   \
         hipLaunchKernelGGL(k, grid, block, lds, stream, x, pregates, w_ih_pk, w_hh_pk, bias, lengths, gates,      \
-                           c_all, h_all, h_final, L, B, ndir, n_tiles);                                           \
+                           c_all, h_all, h_final, L, B, ndir, n_tiles, x_drop_p, x_drop_seed);                    \
     }
     if (!x) GMT_GO(0, H)
     else if (I == H) GMT_GO(1, H + H)
@@ -495,7 +508,8 @@ int launch_fwd(const float* x, const float* pregates, const float* w_ih_pk, cons
 template <int NW>
 int launch_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths, const float* dh_all,
                const float* dh_final, const float* dgates_extra, const float* dc_extra,
-               float* da_out, float* dct_out, float* dht_out, int L, int B, int ndir, hipStream_t stream)
+               float* da_out, float* dct_out, float* dht_out, int L, int B, int ndir,
+               float dy_drop_p, uint32_t dy_drop_seed, hipStream_t stream)
 {
     constexpr int H = NW * 32;
     constexpr bool RES = (NW <= 4);
@@ -504,13 +518,17 @@ int launch_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const in
     if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;
     const bool plain = !dgates_extra && !dc_extra && !da_out && !dct_out && !dht_out;
     const bool extra = dgates_extra && dc_extra;
-    auto k = plain ? (dh_all ? lstm_bwd_kernel<NW, RES, true, true, false> : lstm_bwd_kernel<NW, RES, true, false, false>)
-           : extra ? (dh_all ? lstm_bwd_kernel<NW, RES, false, true, true> : lstm_bwd_kernel<NW, RES, false, false, true>)
-                   : (dh_all ? lstm_bwd_kernel<NW, RES, false, true, false> : lstm_bwd_kernel<NW, RES, false, false, false>);
+    const bool drop = dh_all && dy_drop_p > 0.f;
+    if (drop && !plain) return GMT_ERR_UNSUPPORTED;     // the fused mask exists for the ordinary training call only
+    auto k = plain ? (drop ? lstm_bwd_kernel<NW, RES, true, 2, false>
+                           : dh_all ? lstm_bwd_kernel<NW, RES, true, 1, false> : lstm_bwd_kernel<NW, RES, true, 0, false>)
+           : extra ? (dh_all ? lstm_bwd_kernel<NW, RES, false, 1, true> : lstm_bwd_kernel<NW, RES, false, 0, true>)
+                   : (dh_all ? lstm_bwd_kernel<NW, RES, false, 1, false> : lstm_bwd_kernel<NW, RES, false, 0, false>);
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GMT_ERR_HIP;
     hipLaunchKernelGGL(k, dim3(n_tiles * ndir), dim3(NW * 64), lds, stream, gates, c_all, w_hh_pkT, lengths,
-                       dh_all, dh_final, dgates_extra, dc_extra, da_out, dct_out, dht_out, L, B, ndir, n_tiles);
+                       dh_all, dh_final, dgates_extra, dc_extra, da_out, dct_out, dht_out, L, B, ndir, n_tiles,
+                       dy_drop_p, dy_drop_seed);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }
@@ -531,14 +549,16 @@ extern "C" int gmt_pack_weight(const float* src, float* dst, int K, int k_valid,
 
 extern "C" int gmt_lstm_layer_fwd(const float* x, const float* pregates, const float* w_ih_pk, const float* w_hh_pk,
                                   const float* bias, const int* lengths, float* gates, float* c_all, float* h_all,
-                                  float* h_final, int L, int B, int I, int H, int ndir, hipStream_t stream)
+                                  float* h_final, int L, int B, int I, int H, int ndir,
+                                  float x_dropout_p, unsigned x_dropout_seed, hipStream_t stream)
 {
+    GMT_CHECK_ARG(x_dropout_p >= 0.f && x_dropout_p < 1.f && (x_dropout_p == 0.f || x));
     GMT_CHECK_ARG(w_hh_pk && L >= 1 && B >= GMT_TM && (B % GMT_TM) == 0 && (ndir == 1 || ndir == 2));
     GMT_CHECK_ARG((x != nullptr) != (pregates != nullptr));
     if (x) GMT_CHECK_ARG(w_ih_pk && bias && (I == H || I == 2 * H));
     switch (H) {
 #define GMT_CASE(NW) case NW * 32: return launch_fwd<NW>(x, pregates, w_ih_pk, w_hh_pk, bias, lengths, gates, c_all, \
-                                                         h_all, h_final, L, B, I, ndir, stream);
+                                                         h_all, h_final, L, B, I, ndir, x_dropout_p, x_dropout_seed, stream);
         GMT_CASE(1) GMT_CASE(2) GMT_CASE(4) GMT_CASE(8)
 #undef GMT_CASE
         default: return GMT_ERR_UNSUPPORTED;
@@ -548,12 +568,15 @@ extern "C" int gmt_lstm_layer_fwd(const float* x, const float* pregates, const f
 extern "C" int gmt_lstm_layer_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths,
                                   const float* dh_all, const float* dh_final, const float* dgates_extra,
                                   const float* dc_extra, float* da_out, float* dct_out, float* dht_out,
-                                  int L, int B, int H, int ndir, hipStream_t stream)
+                                  int L, int B, int H, int ndir, float dy_dropout_p, unsigned dy_dropout_seed,
+                                  hipStream_t stream)
 {
+    GMT_CHECK_ARG(dy_dropout_p >= 0.f && dy_dropout_p < 1.f);
     GMT_CHECK_ARG(gates && c_all && w_hh_pkT && L >= 1 && B >= GMT_TM && (B % GMT_TM) == 0 && (ndir == 1 || ndir == 2));
     switch (H) {
 #define GMT_CASE(NW) case NW * 32: return launch_bwd<NW>(gates, c_all, w_hh_pkT, lengths, dh_all, dh_final, \
-                                                         dgates_extra, dc_extra, da_out, dct_out, dht_out, L, B, ndir, stream);
+                                                         dgates_extra, dc_extra, da_out, dct_out, dht_out, L, B, ndir, \
+                                                         dy_dropout_p, dy_dropout_seed, stream);
         GMT_CASE(1) GMT_CASE(2) GMT_CASE(4) GMT_CASE(8)
 #undef GMT_CASE
         default: return GMT_ERR_UNSUPPORTED;

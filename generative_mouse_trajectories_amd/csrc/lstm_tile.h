@@ -48,6 +48,24 @@ __device__ __host__ __forceinline__ uint32_t gmt_hash32(uint32_t x) {
 __device__ __host__ __forceinline__ bool gmt_keep(uint32_t idx, uint32_t seed, uint32_t thresh24) {
     return (gmt_hash32(idx + seed * 0x9E3779B1u) >> 8) >= thresh24;      // P(drop) = thresh24 / 2^24
 }
+// The critic's inter-layer mask: one hash decides two neighbouring elements (16 bits each), so a
+// float4 of the staged operand costs two hashes.  Element e is kept iff the (e & 1)-th half of
+// hash(e >> 1) is >= thresh16; P(drop) = thresh16 / 2^16.
+__device__ __host__ __forceinline__ uint32_t gmt_keep_pair_hash(uint32_t pair, uint32_t seed) {
+    return gmt_hash32(pair + seed * 0x9E3779B1u);
+}
+__device__ __host__ __forceinline__ bool gmt_keep16(uint32_t idx, uint32_t seed, uint32_t thresh16) {
+    const uint32_t h = gmt_keep_pair_hash(idx >> 1, seed);
+    return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= thresh16;
+}
+// x4 = four consecutive elements starting at idx (idx % 4 == 0), scaled or zeroed in place
+__device__ __forceinline__ void gmt_drop4(float4& v, uint32_t idx, uint32_t seed, uint32_t thresh16, float scale) {
+    const uint32_t h0 = gmt_keep_pair_hash(idx >> 1, seed), h1 = gmt_keep_pair_hash((idx >> 1) + 1u, seed);
+    v.x = (h0 & 0xffffu) >= thresh16 ? v.x * scale : 0.f;
+    v.y = (h0 >> 16) >= thresh16 ? v.y * scale : 0.f;
+    v.z = (h1 & 0xffffu) >= thresh16 ? v.z * scale : 0.f;
+    v.w = (h1 >> 16) >= thresh16 ? v.w * scale : 0.f;
+}
 
 // row of accumulator register r for this lane
 __device__ __forceinline__ int gmt_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

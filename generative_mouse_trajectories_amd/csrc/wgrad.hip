@@ -26,8 +26,13 @@ constexpr int WG_RC = 16;                               // rows per chunk
 template <int NB, int QB>
 __global__ __launch_bounds__(256, 2)
 void wgrad_kernel(const float* __restrict__ dA, long long lda, const float* __restrict__ X, long long ldx,
-                  float* __restrict__ slab, float* __restrict__ db_slab, int N, int I, long long R, int ksplit)
+                  float* __restrict__ slab, float* __restrict__ db_slab, int N, int I, long long R, int ksplit,
+                  float x_drop_p, uint32_t x_drop_seed)
 {
+    // X is read through an inverted-dropout mask (the consumer layer applied the same one to its input
+    // in LDS, csrc/lstm_seq.hip): element (r, i) is kept iff gmt_keep16(r*ldx + i, seed).  Wide tiles only.
+    const uint32_t x_thresh16 = (uint32_t)(x_drop_p * 65536.0f);
+    const float x_keep_scale = 1.0f / (1.0f - x_drop_p);
     constexpr int TN = 128 * NB, TI = 32 * QB;
     constexpr int LDA_ = TN + 4, LDX_ = TI + 4;         // LDS pitches (floats): +4 keeps float4 alignment
     constexpr int AC4 = TN / 4, ARG = 256 / AC4, AJ = WG_RC / ARG;   // A staging: float4 columns, row groups, float4 per thread
@@ -88,7 +93,14 @@ void wgrad_kernel(const float* __restrict__ dA, long long lda, const float* __re
             st.rx[0].y = xs_ok ? bX[offX[1]] : 0.f;
         }
     };
-    auto s_store = [&](Stage& st, int buf) {
+    auto s_store = [&](Stage& st, int buf, long long c) {
+        if constexpr (XV) {
+            if (x_thresh16) {                           // uniform
+                const uint32_t i0 = (uint32_t)(c * WG_RC * ldx) + (uint32_t)(it * TI);
+#pragma unroll
+                for (int j = 0; j < XJ; ++j) gmt_drop4(st.rx[j], i0 + offX[j], x_drop_seed, x_thresh16, x_keep_scale);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             *reinterpret_cast<float4*>(&sA[buf][a_r0 + ARG * j][4 * a_c4]) = st.ra[j];
@@ -136,7 +148,7 @@ void wgrad_kernel(const float* __restrict__ dA, long long lda, const float* __re
     const long long cl = c1 - 1;
     if (c0 < c1) {
         g_load(s0, c0);
-        s_store(s0, 0);
+        s_store(s0, 0, c0);
         g_load(s0, c0 + 1 < c1 ? c0 + 1 : cl);
     }
     __syncthreads();
@@ -144,11 +156,11 @@ void wgrad_kernel(const float* __restrict__ dA, long long lda, const float* __re
     for (; c + 1 < c1; c += 2) {                        // LDS[0] = chunk c, s0 = chunk c+1
         g_load(s1, c + 2 < c1 ? c + 2 : cl);
         compute(0);
-        s_store(s0, 1);
+        s_store(s0, 1, c + 1);
         __syncthreads();
         g_load(s0, c + 3 < c1 ? c + 3 : cl);
         compute(1);
-        if (c + 2 < c1) s_store(s1, 0);                 // (a clamped re-read must not reach the column sums)
+        if (c + 2 < c1) s_store(s1, 0, c + 2);               // (a clamped re-read must not reach the column sums)
         __syncthreads();
     }
     if (c < c1) compute(0);                             // odd tail
@@ -266,11 +278,13 @@ extern "C" int gmt_wgrad_workspace_floats(int N, int I, long long R, int* ksplit
 
 extern "C" int gmt_wgrad(const float* dA, long long lda, const float* X, long long ldx, long long R, int N, int I,
                          float* dW, float* db, int accumulate, float* workspace, long long workspace_floats,
-                         hipStream_t stream)
+                         float x_dropout_p, unsigned x_dropout_seed, hipStream_t stream)
 {
     GMT_CHECK_ARG(dA && X && dW && workspace);
+    GMT_CHECK_ARG(x_dropout_p >= 0.f && x_dropout_p < 1.f);
     const int shape = wgrad_shape(N, I, ldx);
     GMT_CHECK_ARG(shape >= 0);
+    if (x_dropout_p > 0.f) GMT_CHECK_ARG(shape <= 1 && R * ldx < (1ll << 32));   // wide tiles; 32-bit mask counter
     GMT_CHECK_ARG((lda % 4) == 0 && (((uintptr_t)dA | (uintptr_t)workspace) & 15) == 0);
     if (shape <= 1) GMT_CHECK_ARG(((uintptr_t)X & 15) == 0);
     int ks = 0; long long need = 0;
@@ -283,10 +297,10 @@ extern "C" int gmt_wgrad(const float* dA, long long lda, const float* X, long lo
     const int tiles = ((N + TN - 1) / TN) * ((I + TI - 1) / TI);
     const int grid = 8 * tiles * ((ks + 7) / 8);
     switch (shape) {
-    case 0: hipLaunchKernelGGL((wgrad_kernel<2, 4>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks); break;
-    case 1: hipLaunchKernelGGL((wgrad_kernel<1, 4>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks); break;
-    case 2: hipLaunchKernelGGL((wgrad_kernel<2, 1>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks); break;
-    default: hipLaunchKernelGGL((wgrad_kernel<1, 1>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks); break;
+    case 0: hipLaunchKernelGGL((wgrad_kernel<2, 4>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks, x_dropout_p, x_dropout_seed); break;
+    case 1: hipLaunchKernelGGL((wgrad_kernel<1, 4>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks, x_dropout_p, x_dropout_seed); break;
+    case 2: hipLaunchKernelGGL((wgrad_kernel<2, 1>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks, x_dropout_p, x_dropout_seed); break;
+    default: hipLaunchKernelGGL((wgrad_kernel<1, 1>), dim3(grid), dim3(256), 0, stream, dA, lda, X, ldx, slab, db_slab, N, I, R, ks, x_dropout_p, x_dropout_seed); break;
     }
     GMT_LAUNCH_CHECK();
     const long long n = (long long)N * I;

@@ -221,20 +221,33 @@ class Discriminator(nn.Module):
                                            SNLinear(H, H // 2), nn.LeakyReLU(0.2), SNLinear(H // 2, 1))
         self.fuse_input_gemm = True
 
-    def forward_tm(self, pos_tm: torch.Tensor, dts_tm: torch.Tensor, lengths_i32: torch.Tensor) -> torch.Tensor:
-        """Time-major core: pos [L,Bp,2], dts [L,Bp], lengths int32 [Bp] (Bp % 32 == 0) -> [Bp,1]."""
+    def forward_tm(self, pos_tm: torch.Tensor, dts_tm: torch.Tensor, lengths_i32: torch.Tensor,
+                   dropout_seed: Optional[int] = None) -> torch.Tensor:
+        """Time-major core: pos [L,Bp,2], dts [L,Bp], lengths int32 [Bp] (Bp % 32 == 0) -> [Bp,1].
+        The inter-layer dropout of nn.LSTM (RG.py:725) is a counter-based mask inside the kernels of the
+        two layers it sits between (ops.LSTMLayerFn in_drop / out_drop; mask of layer l = seed + l,
+        ops.dropout_keep_mask reproduces it) when the layer shapes allow, else F.dropout."""
         feat = ops.kinematics_tm(pos_tm, dts_tm)
         x = self.feature_encoder(feat)
+        H = self.config.discriminator_hidden_dim
         nl = self.config.discriminator_num_layers
+        p = float(self.config.lstm_dropout) if self.training else 0.0
+        fused = p > 0 and self.fuse_input_gemm and (2 * H) % 128 == 0
+        if fused and dropout_seed is None:
+            dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        none = (0.0, 0)
         h_final = None
         for l in range(nl):
-            h_all, h_final = ops.lstm_layer(x, lengths_i32, self.lstm.layer_weights(l), fuse_x=self.fuse_input_gemm)
+            h_all, h_final = ops.lstm_layer(x, lengths_i32, self.lstm.layer_weights(l), fuse_x=self.fuse_input_gemm,
+                                            in_drop=(p, dropout_seed + l) if fused and l > 0 else none,
+                                            out_drop=(p, dropout_seed + l + 1) if fused and l + 1 < nl else none)
             x = h_all
-            if l + 1 < nl and self.training and self.config.lstm_dropout > 0:
-                x = F.dropout(x, self.config.lstm_dropout, True)
+            if l + 1 < nl and p > 0 and not fused:
+                x = F.dropout(x, p, True)
         return self.output_layers(h_final)
 
-    def forward(self, trajectories: torch.Tensor, dts: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+    def forward(self, trajectories: torch.Tensor, dts: torch.Tensor, lengths: torch.Tensor,
+                dropout_seed: Optional[int] = None) -> torch.Tensor:
         """trajectories (B,L,2), dts (B,L), lengths (B,) -> critic scores (B,1)."""
         L_.require_cuda(trajectories, dts)
         B = trajectories.shape[0]
@@ -242,4 +255,4 @@ class Discriminator(nn.Module):
         pos_tm = _pad_batch(trajectories.transpose(0, 1), Bp, 1).contiguous()
         dts_tm = _pad_batch(dts.transpose(0, 1), Bp, 1).contiguous()
         lens = _pad_batch(lengths.to(device=trajectories.device, dtype=torch.int32).clamp(min=1), Bp, 0, 1)
-        return self.forward_tm(pos_tm, dts_tm, lens.contiguous())[:B]
+        return self.forward_tm(pos_tm, dts_tm, lens.contiguous(), dropout_seed)[:B]

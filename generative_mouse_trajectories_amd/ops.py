@@ -38,9 +38,9 @@ def gate_unperm(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(H, 4, -1).transpose(0, 1).reshape(w.shape).contiguous()
 
 
-def wgrad_gates(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False):
+def wgrad_gates(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False, x_drop: Tuple[float, int] = (0.0, 0)):
     """wgrad for a d(pre-activation) buffer (unit-major columns): results in torch's gate-major order."""
-    dW, db = wgrad(dA, X, want_db)
+    dW, db = wgrad(dA, X, want_db, x_drop)
     return gate_unperm(dW), (None if db is None else gate_unperm(db))
 
 
@@ -108,17 +108,20 @@ def pack_transposed(ws: List[torch.Tensor], n_out: int, K: int, col0: int = 0, n
 # ----------------------------------------------------------------------------------------
 # weight-gradient contraction over time (split-K MFMA kernel, csrc/wgrad.hip)
 # ----------------------------------------------------------------------------------------
-def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False):
+def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False, x_drop: Tuple[float, int] = (0.0, 0)):
     """dW = dA^T X over the rows (dA [R,N] contiguous, X [R,I] a row-strided view); optionally
     db = dA.sum(0).  Kernel shapes (csrc/wgrad.hip): N % 4 == 0 and either I % 128 == 0 with a
     16-byte aligned X, or a skinny X (I <= 32, any row pitch); R % 16 == 0.  Anything else goes
-    to rocBLAS."""
+    to rocBLAS.  x_drop = (p, seed): X is read through the fused inter-layer dropout mask
+    (counter r*ldx + i; wide X only - lstm_layer never asks for it otherwise)."""
     R, N = dA.shape
     I = X.shape[1]
     wide = I % 128 == 0 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
     ok = (dA.is_cuda and N % 4 == 0 and R % 16 == 0 and R >= 16 and dA.is_contiguous() and dA.data_ptr() % 16 == 0
           and X.stride(1) == 1 and (wide or I <= 32) and dA.dtype == torch.float32 and X.dtype == torch.float32)
     if not ok:
+        if x_drop[0] > 0:
+            raise L_.GmtError('wgrad: the fused dropout mask needs the split-K kernel (I % 128 == 0, R % 16 == 0)')
         dW = torch.mm(dA.t(), X)
         return dW, (dA.sum(0) if want_db else None)
     import ctypes
@@ -128,7 +131,8 @@ def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False):
     dW = torch.empty(N, I, device=dA.device, dtype=torch.float32)
     db = torch.empty(N, device=dA.device, dtype=torch.float32) if want_db else None
     L_.call('gmt_wgrad', dA.data_ptr(), N, X.data_ptr(), X.stride(0), R, N, I, dW.data_ptr(),
-            None if db is None else db.data_ptr(), 0, ws.data_ptr(), need.value, L_.stream(), label=f'wgrad_N{N}_I{I}')
+            None if db is None else db.data_ptr(), 0, ws.data_ptr(), need.value, float(x_drop[0]), int(x_drop[1]),
+            L_.stream(), label=f'wgrad_N{N}_I{I}')
     return dW, db
 
 
@@ -166,10 +170,14 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch
 # ----------------------------------------------------------------------------------------
 class LSTMLayerFn(torch.autograd.Function):
     """x [L,B,I] (B % 32 == 0), lengths int32 [B] -> (h_all [L,B,nd*H], h_final [B,nd*H]).
-    weights: per direction (w_ih [4H,I], w_hh [4H,H], b_ih [4H], b_hh [4H])."""
+    weights: per direction (w_ih [4H,I], w_hh [4H,H], b_ih [4H], b_hh [4H]).
+    in_drop / out_drop = (p, seed): nn.LSTM's inter-layer dropout (RG.py:725) without a mask tensor.
+    The layer with in_drop reads its input through the mask (forward and dW_ih) and returns dx
+    w.r.t. the DROPPED input; the layer below it is given the same pair as out_drop and applies
+    the mask to that adjoint.  The two must be used together (models.Discriminator does)."""
 
     @staticmethod
-    def forward(ctx, x, lengths, fuse_x, need_h_all, *weights):
+    def forward(ctx, x, lengths, fuse_x, need_h_all, in_drop, out_drop, *weights):
         L_.require_cuda(x)
         nd = len(weights) // 4
         w_ih = [weights[4 * d] for d in range(nd)]
@@ -185,20 +193,23 @@ class LSTMLayerFn(torch.autograd.Function):
         c_all = torch.empty(nd, L, B, H, device=dev, dtype=torch.float32)
         h_all = torch.empty(L, B, nd * H, device=dev, dtype=torch.float32)
         h_final = torch.empty(B, nd * H, device=dev, dtype=torch.float32)
+        if in_drop[0] > 0 and not (fuse_x and I % 128 == 0 and (L * B) % 16 == 0):
+            raise L_.GmtError('fused input dropout needs the fused input contraction and I % 128 == 0')
         if fuse_x:
             w_ih_pk = pack_forward(w_ih, H, I)
             L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(w_ih_pk), L_.ptr(w_hh_pk), L_.ptr(bias),
                     L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
-                    L, B, I, H, nd, L_.stream(), label=f'lstm_fwd_fused_I{I // H}')
+                    L, B, I, H, nd, float(in_drop[0]), int(in_drop[1]), L_.stream(), label=f'lstm_fwd_fused_I{I // H}')
         else:
             x2 = x.view(L * B, I)
             for d in range(nd):
                 torch.addmm(gate_perm(bias[d]), x2, gate_perm(w_ih[d].detach()).t(), out=gates[d].view(L * B, 4 * H))
             L_.call('gmt_lstm_layer_fwd', None, L_.ptr(gates), None, L_.ptr(w_hh_pk), None,
                     L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
-                    L, B, I, H, nd, L_.stream(), label='lstm_fwd_pregates')
+                    L, B, I, H, nd, 0.0, 0, L_.stream(), label='lstm_fwd_pregates')
         ctx.save_for_backward(x, lengths, gates, c_all, h_all, *weights)
         ctx.dims = (L, B, I, H, nd)
+        ctx.drops = (in_drop, out_drop)
         ctx.set_materialize_grads(False)
         return h_all, h_final
 
@@ -206,6 +217,7 @@ class LSTMLayerFn(torch.autograd.Function):
     def backward(ctx, dh_all, dh_final):
         x, lengths, gates, c_all, h_all, *weights = ctx.saved_tensors
         L, B, I, H, nd = ctx.dims
+        in_drop, out_drop = ctx.drops
         w_ih = [weights[4 * d] for d in range(nd)]
         w_hh = [weights[4 * d + 1] for d in range(nd)]
         if dh_all is not None:
@@ -215,7 +227,8 @@ class LSTMLayerFn(torch.autograd.Function):
         w_hh_pkT = pack_transposed(w_hh, H, 4 * H)
         # `gates` is overwritten in place with d(pre-activation): the graph can be back-propagated once
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
-                L_.ptr(dh_all), L_.ptr(dh_final), None, None, None, None, None, L, B, H, nd, L_.stream(), label='lstm_bwd')
+                L_.ptr(dh_all), L_.ptr(dh_final), None, None, None, None, None, L, B, H, nd,
+                float(out_drop[0]), int(out_drop[1]), L_.stream(), label='lstm_bwd')
         da = gates
         x2 = x.view(L * B, I)
         grads: List[Optional[torch.Tensor]] = []
@@ -225,24 +238,25 @@ class LSTMLayerFn(torch.autograd.Function):
             for d in range(1, nd):
                 dx.addmm_(da[d].view(L * B, 4 * H), gate_perm(w_ih[d].detach()))
             dx = dx.view(L, B, I)
-        need_w = any(ctx.needs_input_grad[4:])
+        need_w = any(ctx.needs_input_grad[6:])
         if need_w:
-            grads = _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd)
+            grads = _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd, in_drop)
         else:
             grads = [None] * (4 * nd)
-        return (dx, None, None, None, *grads)
+        return (dx, None, None, None, None, None, *grads)
 
 
-def lstm_layer(x, lengths_i32, weights, fuse_x: bool = True, need_h_all: bool = True):
-    return LSTMLayerFn.apply(x, lengths_i32, fuse_x, need_h_all, *weights)
+def lstm_layer(x, lengths_i32, weights, fuse_x: bool = True, need_h_all: bool = True,
+               in_drop: Tuple[float, int] = (0.0, 0), out_drop: Tuple[float, int] = (0.0, 0)):
+    return LSTMLayerFn.apply(x, lengths_i32, fuse_x, need_h_all, in_drop, out_drop, *weights)
 
 
-def _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd):
+def _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd, x_drop=(0.0, 0)):
     """dW_ih, dW_hh, db per direction from d(pre-activation) [nd,L,B,4H] (one contraction each)."""
     grads = []
     for d in range(nd):
         da2 = da[d].view(L * B, 4 * H)
-        d_wih, db = wgrad_gates(da2, x2, want_db=True)
+        d_wih, db = wgrad_gates(da2, x2, want_db=True, x_drop=x_drop)
         hv = h_all.view(L * B, nd * H)[:, d * H:(d + 1) * H]
         if L > 1:
             # forward direction: h_prev(t) = h[t-1]; reverse: h_prev(t) = h[t+1] (zero beyond the row's length)
@@ -275,7 +289,7 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         w_hh_pkT = pack_transposed(w_hh, H, 4 * H)
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
                 L_.ptr(dh_all), L_.ptr(dh_final), None, None, L_.ptr(da), L_.ptr(dct), L_.ptr(dht),
-                L, B, H, nd, L_.stream(), label='lstm_bwd_gp')
+                L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp')
         dx = torch.mm(da[0].view(L * B, 4 * H), gate_perm(w_ih[0].detach()))
         for d in range(1, nd):
             dx.addmm_(da[d].view(L * B, 4 * H), gate_perm(w_ih[d].detach()))
@@ -338,7 +352,7 @@ class LSTMLayerGPFn(torch.autograd.Function):
         w_hh_pk = pack_forward(w_hh, H, H)
         L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(w_ih_pk), L_.ptr(w_hh_pk),
                 L_.ptr(bias), L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
-                L, B, I, H, nd, L_.stream(), label=f'lstm_fwd_gp_I{I // H}')
+                L, B, I, H, nd, 0.0, 0, L_.stream(), label=f'lstm_fwd_gp_I{I // H}')
         ctx.save_for_backward(x, lengths, gates, c_all, h_all, *weights)
         ctx.dims = (L, B, I, H, nd)
         ctx.set_materialize_grads(False)
@@ -362,7 +376,7 @@ class LSTMLayerGPFn(torch.autograd.Function):
         w_hh_pkT = pack_transposed(w_hh, H, 4 * H)
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
                 L_.ptr(dh_all), L_.ptr(dh_final), L_.ptr(dgates), L_.ptr(dc), L_.ptr(da), None, None,
-                L, B, H, nd, L_.stream(), label='lstm_bwd_gp2')
+                L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp2')
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.mm(da[0].view(L * B, 4 * H), gate_perm(w_ih[0].detach()))
@@ -511,14 +525,22 @@ def ctypes_byref(a):
     return ctypes.cast(ctypes.pointer(a), ctypes.c_void_p)
 
 
-def dropout_keep_mask(T: int, B: int, H: int, p: float, seed: int) -> torch.Tensor:
-    """Host replica of the kernels' counter-based dropout mask (csrc/lstm_tile.h gmt_keep):
-    [T,B,H] float mask of 0 / 1/(1-p).  Used by the tests to feed the oracle the same mask."""
+def dropout_keep_mask(T: int, B: int, H: int, p: float, seed: int, pair16: bool = False) -> torch.Tensor:
+    """Host replica of the kernels' counter-based dropout masks (csrc/lstm_tile.h): [T,B,H] float mask
+    of 0 / 1/(1-p).  pair16=False: gmt_keep (generator rollout, one 24-bit draw per element);
+    pair16=True: gmt_keep16 (critic inter-layer mask, two 16-bit draws per hash).  Used by the tests
+    to feed the oracle the same mask."""
     import numpy as np
+    u = np.uint64
     idx = np.arange(T * B * H, dtype=np.uint64)
-    x = (idx + (np.uint64(seed & 0xFFFFFFFF) * np.uint64(0x9E3779B1))) & np.uint64(0xFFFFFFFF)
-    x = (x * np.uint64(747796405) + np.uint64(2891336453)) & np.uint64(0xFFFFFFFF)
-    w = (((x >> ((x >> np.uint64(28)) + np.uint64(4))) ^ x) * np.uint64(277803737)) & np.uint64(0xFFFFFFFF)
-    h = ((w >> np.uint64(22)) ^ w) & np.uint64(0xFFFFFFFF)
-    keep = (h >> np.uint64(8)) >= np.uint64(int(np.float32(p) * np.float32(16777216.0)))
+    ctr = idx >> u(1) if pair16 else idx
+    x = (ctr + (u(seed & 0xFFFFFFFF) * u(0x9E3779B1))) & u(0xFFFFFFFF)
+    x = (x * u(747796405) + u(2891336453)) & u(0xFFFFFFFF)
+    w = (((x >> ((x >> u(28)) + u(4))) ^ x) * u(277803737)) & u(0xFFFFFFFF)
+    h = ((w >> u(22)) ^ w) & u(0xFFFFFFFF)
+    if pair16:
+        half = np.where((idx & u(1)) == u(1), h >> u(16), h & u(0xFFFF))
+        keep = half >= u(int(np.float32(p) * np.float32(65536.0)))
+    else:
+        keep = (h >> u(8)) >= u(int(np.float32(p) * np.float32(16777216.0)))
     return torch.from_numpy((keep.astype(np.float32) / np.float32(1.0 - p)).reshape(T, B, H))

@@ -103,10 +103,16 @@ int gmt_pack_weight(const float* src, float* dst, int K, int k_valid, int n_vali
  * uses the weight with its 4H axis permuted the same way (row 4*u+g <- torch row g*H+u).
  * outputs (each may be NULL): gates [ndir][L][B][4H] activated i,f,g,o (may alias
  * pregates), c_all [ndir][L][B][H], h_all [L][B][ndir*H] (zero at padded steps),
- * h_final [B][ndir*H] (forward: state at len-1; reverse: state after t = 0, RG.py:776-778). */
+ * h_final [B][ndir*H] (forward: state at len-1; reverse: state after t = 0, RG.py:776-778).
+ * x_dropout_p > 0 (needs x): nn.LSTM's inter-layer dropout (RG.py:725) fused into the CONSUMING
+ * layer - element e of x (flat index into [L][B][I]) is read as x[e]/(1-p) if
+ * hash(e, x_dropout_seed) keeps it, else 0 (counter-based mask, csrc/lstm_tile.h gmt_keep16; no mask
+ * tensor exists).  The same (p, seed) then goes to the producing layer's gmt_lstm_layer_bwd and to
+ * gmt_wgrad for this layer's dW_ih. */
 int gmt_lstm_layer_fwd(const float* x, const float* pregates, const float* w_ih_pk, const float* w_hh_pk,
                        const float* bias, const int* lengths, float* gates, float* c_all, float* h_all,
-                       float* h_final, int L, int B, int I, int H, int ndir, hipStream_t stream);
+                       float* h_final, int L, int B, int I, int H, int ndir,
+                       float x_dropout_p, unsigned x_dropout_seed, hipStream_t stream);
 
 /* gmt_lstm_layer_bwd: reverse sweep of the same layer (what autograd does for RG.py:1021,
  * 1109).  In: gates / c_all saved by the forward, dh_all [L][B][ndir*H] and / or dh_final
@@ -116,11 +122,15 @@ int gmt_lstm_layer_fwd(const float* x, const float* pregates, const float* w_ih_
  * dgates_extra / dc_extra: optional additional adjoints of the saved activations (used by
  * the gradient-penalty double backward).  da_out: when non-NULL, d(pre-activation) goes
  * there and `gates` is left intact; dct_out / dht_out [ndir][L][B][H]: optional, the total
- * cell / hidden adjoint of every step (inputs of gmt_lstm_layer_bwd2).  H in {32,64,128,256}. */
+ * cell / hidden adjoint of every step (inputs of gmt_lstm_layer_bwd2).  H in {32,64,128,256}.
+ * dy_dropout_p > 0: dh_all is the adjoint of the DROPPED output (the next layer ran with
+ * x_dropout_p): element e of dh_all is read through the same mask.  Ordinary call only (no
+ * extra adjoints / outputs). */
 int gmt_lstm_layer_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths,
                        const float* dh_all, const float* dh_final, const float* dgates_extra,
                        const float* dc_extra, float* da_out, float* dct_out, float* dht_out,
-                       int L, int B, int H, int ndir, hipStream_t stream);
+                       int L, int B, int H, int ndir, float dy_dropout_p, unsigned dy_dropout_seed,
+                       hipStream_t stream);
 
 /* gmt_lstm_layer_bwd2: adjoint of gmt_lstm_layer_bwd itself - the LSTM part of
  * torch.autograd.grad(..., create_graph=True) in compute_gradient_penalty, RG.py:829-835.
@@ -139,11 +149,13 @@ int gmt_lstm_layer_bwd2(const float* xhat, const float* w_ih_pk, const float* w_
  * dW_ih / dW_hh / db GEMMs autograd runs for RG.py:1021, 1109.  Split-K fp32-MFMA kernel with a
  * deterministic slab reduction.  N % 256 == 0, I % 128 == 0, R % 32 == 0; lda / ldx = row
  * pitches in floats (multiples of 4); db may be NULL; accumulate != 0 adds to dW / db.
- * gmt_wgrad_workspace_floats tells the caller how large `workspace` must be. */
+ * gmt_wgrad_workspace_floats tells the caller how large `workspace` must be.
+ * x_dropout_p > 0 (I % 128 == 0 only): X is read through the dropout mask of gmt_lstm_layer_fwd,
+ * element (r, i) with counter r*ldx + i. */
 int gmt_wgrad_workspace_floats(int N, int I, long long R, int* ksplit_out, long long* floats_out);
 int gmt_wgrad(const float* dA, long long lda, const float* X, long long ldx, long long R, int N, int I,
               float* dW, float* db, int accumulate, float* workspace, long long workspace_floats,
-              hipStream_t stream);
+              float x_dropout_p, unsigned x_dropout_seed, hipStream_t stream);
 
 /* ---- persistent generator rollout -----------------------------------------------------------
  * Replaces the autoregressive loop of Generator.forward, RG.py:508-604 (dynamic features

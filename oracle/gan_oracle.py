@@ -266,9 +266,11 @@ def _masked_lstm_dir(x_seq: Tensor, lengths: Tensor, w_ih, w_hh, b_ih, b_hh, rev
 def discriminator_forward(P: Params, bufs: Params, traj, dts, lengths, training: bool = True,
                           lstm_dropout: float = 0.0, head_dropout: float = 0.0,
                           gen: Optional[torch.Generator] = None, num_layers: int = 2,
-                          return_intermediates: bool = False):
+                          return_intermediates: bool = False, lstm_dropout_masks=None):
     """RG.py:739-783.  `bufs` holds weight_u / weight_v and is advanced in place
-    when training (one power iteration per call)."""
+    when training (one power iteration per call).  lstm_dropout_masks: optional explicit
+    multiplicative masks [B,L,2H] (0 or 1/(1-p)), one per layer boundary, in place of drawn ones
+    (the tests hand over the mask the HIP kernels derive from their counter-based hash)."""
     def snw(name):
         return sn_weight(P[name + '.weight_orig'], bufs[name + '.weight_u'],
                          bufs[name + '.weight_v'], training)
@@ -286,7 +288,7 @@ def discriminator_forward(P: Params, bufs: Params, traj, dts, lengths, training:
                                   P[f'lstm.bias_ih_l{l}_reverse'], P[f'lstm.bias_hh_l{l}_reverse'], True)
         x = torch.cat([of, ob], dim=-1)
         if l + 1 < num_layers:
-            x = _dropout(x, lstm_dropout, gen)
+            x = x * lstm_dropout_masks[l].to(x.dtype) if lstm_dropout_masks is not None else _dropout(x, lstm_dropout, gen)
     hcomb = torch.cat([hf, hb], dim=-1)                           # RG.py:776-778
     y = F.leaky_relu(F.linear(hcomb, snw('output_layers.0'), P['output_layers.0.bias']), 0.2)
     y = _dropout(y, head_dropout, gen)

@@ -16,7 +16,7 @@ int main()
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
-        int rc = gmt_lstm_layer_bwd(gates, c, w, nullptr, dh, dhf, nullptr, nullptr, nullptr, nullptr, nullptr, L, B, H, ndir, 0);
+        int rc = gmt_lstm_layer_bwd(gates, c, w, nullptr, dh, dhf, nullptr, nullptr, nullptr, nullptr, nullptr, L, B, H, ndir, 0.f, 0u, 0);
         CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
         if (rc) { printf("rc %d\n", rc); return 1; }
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));

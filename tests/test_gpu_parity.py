@@ -180,6 +180,50 @@ def test_generator_fused_dropout_matches_oracle_with_same_mask(over, B, T):
         H.assert_close(p.grad, g_ref, 2e-4, f'G bwd with dropout {k}')
 
 
+H64 = dict(latent_dim=16, generator_hidden_dim=64, discriminator_hidden_dim=64)
+
+
+@pytest.mark.parametrize('over,B,T', [(H.MID, 8, 12), (H64, 40, 10), (H.DEFAULT, 4, 8)])
+def test_discriminator_fused_dropout_matches_oracle_with_same_mask(over, B, T):
+    """The dropout between the critic's two LSTM layers (RG.py:725) never exists as a tensor: layer 1
+    reads its input through a counter-based mask (forward kernel and dW_ih contraction) and layer 0's
+    backward sweep applies the same mask to the adjoint it receives.  The oracle, handed the host replica
+    of that mask, must give the same scores, parameter gradients and input gradients."""
+    from generative_mouse_trajectories_amd import ops
+    gmt, cfg, G, D = build(over, 41, 42)
+    cfg.lstm_dropout = 0.25
+    seed = 777
+    lengths = sorted(np.random.default_rng(5).integers(1, T + 1, B).tolist(), reverse=True)
+    b = H.batch_t(B, T, 43, lengths)
+    traj = gmt.trajectory_to_absolute(b['starts'], b['sequences'][:, :, :2])
+    dts = torch.nn.functional.pad(b['sequences'][:, :, 2], (1, 0), value=0.001)
+    lp1 = b['lengths'] + 1
+    w = torch.randn(B, 1, generator=torch.Generator().manual_seed(6))
+    sd0 = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    trajg, dtsg = traj.to(DEV).requires_grad_(True), dts.to(DEV).requires_grad_(True)
+    D.zero_grad()
+    score = D(trajg, dtsg, lp1.to(DEV), dropout_seed=seed)
+    (score * w.to(DEV)).sum().backward()
+
+    Hd = cfg.discriminator_hidden_dim
+    dm = ops.dropout_keep_mask(T + 1, ops.pad_rows(B), 2 * Hd, cfg.lstm_dropout, seed + 1, pair16=True)[:, :B].transpose(0, 1)
+    kept = float((dm > 0).double().mean())
+    assert abs(kept - 0.75) < 0.08, kept
+    names = {k for k, _ in D.named_parameters()}
+    P = {k: v.clone().requires_grad_(True) for k, v in sd0.items() if k in names}
+    bufs = {k: v.clone() for k, v in sd0.items() if k not in names}
+    tr, dr = traj.clone().requires_grad_(True), dts.clone().requires_grad_(True)
+    ref = O.discriminator_forward(P, bufs, tr, dr, lp1, training=True, lstm_dropout_masks=[dm])
+    H.assert_close(score, ref.detach(), 5e-5, 'D score with dropout')
+    keys = list(P.keys())
+    gr = torch.autograd.grad((ref * w).sum(), [P[k] for k in keys] + [tr, dr])
+    got = dict(D.named_parameters())
+    for k, g_ref in zip(keys, gr):
+        H.assert_close(got[k].grad, g_ref, 2e-4, f'D grad with dropout {k}')
+    H.assert_close(trajg.grad, gr[-2], 2e-4, 'D gtraj with dropout')
+    H.assert_close(dtsg.grad, gr[-1], 2e-4, 'D gdts with dropout')
+
+
 def test_overlapped_generator_forward_is_the_same_step():
     """Trainer.overlap_g_forward launches the G step's rollout during the D step (second stream).
     With the noise it drew fed to an ordinary trainer, both give the same G step."""
