@@ -4,6 +4,6 @@ jrcalgo/generative-mouse-trajectories, behind the reference's own Python surface
 compute_kinematics, trajectory_to_absolute, compute_gradient_penalty,
 MouseTrajectoryDataset, collate_trajectories.  GPU only; see DESIGN.md."""
 from .config import Config  # noqa: F401
-from .data import MouseTrajectoryDataset, collate_trajectories  # noqa: F401
+from .data import LengthBucketedBatchSampler, MouseTrajectoryDataset, collate_trajectories  # noqa: F401
 from .models import Discriminator, Generator, compute_kinematics, trajectory_to_absolute  # noqa: F401
 from .trainer import Trainer, compute_gradient_penalty  # noqa: F401

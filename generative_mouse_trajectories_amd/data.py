@@ -6,11 +6,11 @@ from __future__ import annotations
 
 import csv
 from pathlib import Path
-from typing import Dict, List
+from typing import Dict, Iterator, List, Sequence
 
 import numpy as np
 import torch
-from torch.utils.data import Dataset
+from torch.utils.data import Dataset, Sampler
 
 from .config import Config
 
@@ -94,3 +94,57 @@ def collate_trajectories(batch: List[Dict]) -> Dict:
         seq[i, :n, 2] = it['dts']
     return {'starts': torch.stack([it['start'] for it in batch]), 'ends': torch.stack([it['end'] for it in batch]),
             'sequences': seq, 'lengths': torch.tensor([it['length'] for it in batch])}
+
+
+class LengthBucketedBatchSampler(Sampler):
+    """Batches of trajectories of similar length (not in the reference, which draws batches at
+    random and pads each to its longest member, RG.py:301 - and the critic then encodes and runs
+    its LSTM over every padded position, RG.py:761).  The persistent kernels skip whole steps only
+    beyond the longest row of a 32-trajectory tile, so what padding costs is set by how ragged a
+    batch is.  Indices are sorted by length, cut into batches, and the batches (not their
+    content) are shuffled each epoch; with `jitter` > 0 the sort key is perturbed so that batch
+    membership also changes between epochs.
+
+        DataLoader(ds, batch_sampler=LengthBucketedBatchSampler(lengths, 64), collate_fn=collate_trajectories)
+
+    Every index appears exactly once per epoch; the last batch may be short unless drop_last."""
+
+    def __init__(self, lengths: Sequence[int], batch_size: int, shuffle: bool = True, drop_last: bool = False,
+                 jitter: float = 0.0, seed: int = 0):
+        self.lengths = np.asarray(lengths, np.float64)
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
+        self.jitter, self.seed, self.epoch = float(jitter), int(seed), 0
+
+    @classmethod
+    def from_dataset(cls, dataset: 'MouseTrajectoryDataset', batch_size: int, **kw) -> 'LengthBucketedBatchSampler':
+        return cls([tr['length'] for tr in dataset.trajectories], batch_size, **kw)
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def __len__(self) -> int:
+        n, b = len(self.lengths), self.batch_size
+        return n // b if self.drop_last else (n + b - 1) // b
+
+    def __iter__(self) -> Iterator[List[int]]:
+        rng = np.random.default_rng([self.seed, self.epoch])
+        key = self.lengths
+        if self.jitter > 0:
+            key = key * (1.0 + self.jitter * rng.uniform(-1.0, 1.0, len(key)))
+        order = np.argsort(-key, kind='stable')
+        b = self.batch_size
+        batches = [order[i:i + b].tolist() for i in range(0, len(order), b)]
+        if self.drop_last and batches and len(batches[-1]) < b:
+            batches.pop()
+        if self.shuffle:
+            batches = [batches[i] for i in rng.permutation(len(batches))]
+        self.epoch += 1
+        return iter(batches)
+
+
+def padding_fraction(lengths: Sequence[int], batches: Sequence[Sequence[int]]) -> float:
+    """Share of padded (wasted) positions when each batch is padded to its longest member."""
+    lengths = np.asarray(lengths)
+    used = sum(int(lengths[list(b)].sum()) for b in batches)
+    padded = sum(int(lengths[list(b)].max()) * len(b) for b in batches)
+    return 1.0 - used / max(padded, 1)

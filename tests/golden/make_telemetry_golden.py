@@ -32,6 +32,24 @@ def main():
                         file_id=np.array(file_id, np.int8), left_click=np.array(clicks),
                         files=np.array([os.path.basename(f) for f in files]))
     print(a.shape)
+    # a verbatim excerpt (data rows only: the reference's recorded CSV text) for the reader / writer tests:
+    # the first three collections of the oldest and of the newest recording
+    lines = []
+    for f in (files[0], files[-1]):
+        with open(f) as fh:
+            header = fh.readline()
+            if not lines:
+                lines.append(header)
+            n_coll = 0
+            for ln in fh:
+                if ln.split(',')[1] == '0':
+                    n_coll += 1
+                    if n_coll > 3:
+                        break
+                lines.append(ln)
+    with open(os.path.join(HERE, 'telemetry_sample.csv'), 'w', newline='') as fh:
+        fh.writelines(lines)
+    print(len(lines) - 1, 'sample rows')
 
 
 if __name__ == '__main__':

@@ -90,6 +90,40 @@ def test_dataset_and_collate_contract(tmp_path):
     assert torch.allclose(ds[n]['start'][0], 1.0 - t0['start'][0])
 
 
+def test_length_bucketed_batches_cut_padding(tmp_path):
+    """batches of similar length, every trajectory once per epoch, usable as a
+    DataLoader batch_sampler with the reference's collate function."""
+    import generative_mouse_trajectories_amd as gmt
+    from generative_mouse_trajectories_amd.data import padding_fraction
+    from torch.utils.data import DataLoader
+    sample = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'telemetry_sample.csv')
+    cfg = gmt.Config()
+    cfg.min_trajectory_length = 3
+    ds = gmt.MouseTrajectoryDataset(sample, cfg)
+    assert len(ds) == 6 * 4
+    bs = gmt.LengthBucketedBatchSampler.from_dataset(ds, 4, seed=1)
+    seen = []
+    for b in DataLoader(ds, batch_sampler=bs, collate_fn=gmt.collate_trajectories):
+        L = b['lengths']
+        assert int(L[0]) == b['sequences'].shape[1] and torch.all(L[:-1] >= L[1:])
+        seen.append(L.tolist())
+    assert len(seen) == len(bs) == 6
+    # the four mirrored copies of a trajectory have its length: bucketed batches of 4 are padding-free here
+    assert all(len(set(l)) == 1 for l in seen)
+
+    lengths = np.random.default_rng(0).integers(5, 200, 1000)
+    s = gmt.LengthBucketedBatchSampler(lengths, 64, jitter=0.05, seed=3)
+    e0, e1 = list(s), list(s)
+    assert sorted(i for b in e0 for i in b) == list(range(1000)) and len(e0) == len(s) == 16
+    assert sorted(i for b in e1 for i in b) == list(range(1000)) and e0 != e1
+    rnd = np.random.default_rng(1).permutation(1000)
+    random_batches = [rnd[i:i + 64] for i in range(0, 1000, 64)]
+    assert padding_fraction(lengths, e0) < 0.12 < 0.3 < padding_fraction(lengths, random_batches)
+    assert len(gmt.LengthBucketedBatchSampler(lengths, 64, drop_last=True)) == 15
+    s2 = gmt.LengthBucketedBatchSampler(lengths, 64, jitter=0.05, seed=3)
+    assert list(s2) == e0                                # same seed, same epoch: same batches
+
+
 def test_teacher_forcing_schedule():
     oc = O.OracleConfig()
     assert O.teacher_forcing_ratio(0, oc) == 1.0
