@@ -128,6 +128,25 @@ def _make_writer(log_dir: str):
         return _NullWriter()
 
 
+def load_checkpoint_file(path: str, map_location=None) -> Dict:
+    """torch.load(weights_only=True) of a checkpoint written by this Trainer OR by the reference.
+    The reference stores its Config *instance* (RG.py:1219), pickled by qualified name - `__main__.Config`
+    when RecurrentGAN.py ran as a script - and loads with weights_only=False (RG.py:1231).  Nothing of the
+    file is executed here: the restricted unpickler is only allowed to build an inert stand-in object for
+    that one name, whose attributes come back as a plain dict under 'config'."""
+    stand_ins = []
+    for mod in ('__main__', 'RecurrentGAN', 'learning.RecurrentGAN', 'python.learning.RecurrentGAN'):
+        cls = type('Config', (), {})
+        cls.__module__, cls.__qualname__ = mod, 'Config'
+        stand_ins.append(cls)
+    with torch.serialization.safe_globals(stand_ins):
+        ckpt = torch.load(path, map_location=map_location, weights_only=True)
+    cfg = ckpt.get('config')
+    if cfg is not None and not isinstance(cfg, dict):
+        ckpt['config'] = dict(vars(cfg))         # instance attributes only: class-level defaults are not pickled
+    return ckpt
+
+
 # ------------------------------------------------------------------------------------------
 # gradient penalty (RecurrentGAN.py:790-842)
 # ------------------------------------------------------------------------------------------
@@ -376,7 +395,7 @@ class Trainer:
             torch.save(checkpoint, path.replace('.pt', '_best.pt'))
 
     def load_checkpoint(self, path: str) -> None:
-        checkpoint = torch.load(path, map_location=self.device, weights_only=True)
+        checkpoint = load_checkpoint_file(path, self.device)
         self.epoch = checkpoint['epoch']
         self.generator.load_state_dict(checkpoint['generator_state_dict'])
         self._g_version += 1

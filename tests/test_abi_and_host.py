@@ -124,6 +124,63 @@ def test_length_bucketed_batches_cut_padding(tmp_path):
     assert list(s2) == e0                                # same seed, same epoch: same batches
 
 
+REF_STYLE_CKPT = '''
+# what RG.py:1211-1227 writes when RecurrentGAN.py runs as a script: the Config INSTANCE is pickled as
+# __main__.Config, optimizers are torch.optim.Adam over module.parameters()
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+import generative_mouse_trajectories_amd as gmt
+class Config(gmt.Config):
+    pass
+cfg = Config(); cfg.batch_size = 32
+torch.manual_seed(5)
+G, D = gmt.Generator(cfg), gmt.Discriminator(cfg)
+opts = []
+for m in (G, D):
+    o = torch.optim.Adam(m.parameters(), lr=cfg.learning_rate, betas=cfg.betas)
+    for _ in range(3):
+        for p in m.parameters():
+            p.grad = torch.randn_like(p)
+        o.step()
+    opts.append(o)
+torch.save({'epoch': 7, 'generator_state_dict': G.state_dict(), 'discriminator_state_dict': D.state_dict(),
+            'g_optimizer_state_dict': opts[0].state_dict(), 'd_optimizer_state_dict': opts[1].state_dict(),
+            'config': cfg, 'best_loss': 0.25}, sys.argv[1])
+'''
+
+
+def make_ref_style_checkpoint(tmp_path):
+    import subprocess
+    import sys
+    script, ckpt = tmp_path / 'mk.py', tmp_path / 'ref_style.pt'
+    script.write_text(REF_STYLE_CKPT)
+    subprocess.check_call([sys.executable, str(script), str(ckpt), ROOT])
+    return str(ckpt)
+
+
+def test_reference_style_checkpoint_loads_without_unpickling_code(tmp_path):
+    """SURVEY.md section 8(f4): the reference pickles its Config instance into the checkpoint and loads
+    with weights_only=False; here the file is read with the restricted unpickler only."""
+    import pickle
+    from generative_mouse_trajectories_amd.trainer import load_checkpoint_file
+    path = make_ref_style_checkpoint(tmp_path)
+    with pytest.raises(pickle.UnpicklingError):
+        torch.load(path, weights_only=True)              # refused as is: __main__.Config
+    c = load_checkpoint_file(path, 'cpu')
+    assert c['epoch'] == 7 and c['best_loss'] == 0.25 and c['config'] == {'batch_size': 32}
+    assert 'lstm.weight_ih_l1_reverse' in c['discriminator_state_dict']
+    st = c['d_optimizer_state_dict']['state']
+    assert len(st) == 26 and float(st[0]['step']) == 3.0
+    # anything else in the file stays refused
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('true',))
+    bad = tmp_path / 'bad.pt'
+    torch.save({'epoch': 0, 'config': Evil()}, str(bad))
+    with pytest.raises(pickle.UnpicklingError):
+        load_checkpoint_file(str(bad), 'cpu')
+
+
 def test_teacher_forcing_schedule():
     oc = O.OracleConfig()
     assert O.teacher_forcing_ratio(0, oc) == 1.0
