@@ -10,7 +10,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libgmt_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 ERRORS = {-1: 'bad argument (null pointer / shape / alignment)', -2: 'unsupported configuration',
@@ -38,6 +38,16 @@ class GenBwdArgs(ctypes.Structure):
                                                 ('seed', ctypes.c_uint)]
 
 
+class SnFwdLayer(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in ('w_orig', 'u', 'v', 'w_out', 'sigma', 'uv_saved')] + [('out_features', c_i), ('in_features', c_i)]
+
+
+class SnBwdLayer(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in ('d_w_sn', 'w_orig', 'uv_saved', 'sigma', 'd_w_orig')] + [('out_features', c_i), ('in_features', c_i)]
+
+
+SN_MAX_LAYERS = 8
+
 _SIGS = {
     'gmt_version': [],
     'gmt_kinematics_fwd': [c_p, c_p, c_p, c_i, c_i, c_f, c_p],
@@ -51,6 +61,8 @@ _SIGS = {
     'gmt_lstm_layer_bwd2': [c_p] * 12 + [c_i] * 5 + [c_p],
     'gmt_wgrad_workspace_floats': [c_i, c_i, c_ll, c_p, c_p],
     'gmt_wgrad': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_ll, c_f, ctypes.c_uint, c_p],
+    'gmt_spectral_norm_fwd': [c_p, c_i, c_f, c_i, c_p],
+    'gmt_spectral_norm_bwd': [c_p, c_i, c_p],
     'gmt_gen_rollout_fwd': [c_p, c_p],
     'gmt_gen_rollout_bwd': [c_p, c_p],
 }

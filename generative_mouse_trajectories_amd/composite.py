@@ -83,7 +83,8 @@ def discriminator_forward_gp(D, trajectories: torch.Tensor, dts: torch.Tensor, l
     """Twice-differentiable discriminator forward for the gradient penalty: the BiLSTM runs in
     the HIP kernels (ops.LSTMLayerGPFn: forward, first backward and the second-order sweep
     are each one persistent launch per layer); the cheap non-recurrent pieces (kinematic
-    features, spectral-norm linears) are torch ops, which autograd differentiates twice."""
+    features, the Linear layers) are torch ops, which autograd differentiates twice; the spectral-norm
+    weights come from gmt_spectral_norm_fwd and are only differentiated once (they do not depend on the input)."""
     from . import ops
     from .models import _pad_batch
     L_.require_cuda(trajectories, dts)
@@ -93,7 +94,8 @@ def discriminator_forward_gp(D, trajectories: torch.Tensor, dts: torch.Tensor, l
     pos = _pad_batch(trajectories.transpose(0, 1), Bp, 1)
     d = _pad_batch(dts.transpose(0, 1), Bp, 1)
     lens = _pad_batch(lengths.to(device=trajectories.device, dtype=torch.int32).clamp(min=1), Bp, 0, 1).contiguous()
-    x = D.feature_encoder(kinematics_torch(pos, d))
+    sn_w = D.spectral_weights()
+    x = D.run_sequential(D.feature_encoder, kinematics_torch(pos, d), sn_w)
     nl = cfg.discriminator_num_layers
     h_final = None
     for l in range(nl):
@@ -101,4 +103,4 @@ def discriminator_forward_gp(D, trajectories: torch.Tensor, dts: torch.Tensor, l
         x = h_all
         if l + 1 < nl and D.training and cfg.lstm_dropout > 0:
             x = F.dropout(x, cfg.lstm_dropout, True)
-    return D.output_layers(h_final[:B])
+    return D.run_sequential(D.output_layers, h_final[:B], sn_w)

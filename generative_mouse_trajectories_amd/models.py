@@ -62,21 +62,15 @@ class SNLinear(nn.Module):
         self.register_buffer('weight_v', v)
 
     def compute_weight(self) -> torch.Tensor:
-        w = self.weight_orig
-        u, v = self.weight_u, self.weight_v
-        if self.training:
-            with torch.no_grad():
-                v = F.normalize(torch.mv(w.t(), u), dim=0, eps=self.eps, out=v)
-                u = F.normalize(torch.mv(w, v), dim=0, eps=self.eps, out=u)
-                u = u.clone(memory_format=torch.contiguous_format)
-                v = v.clone(memory_format=torch.contiguous_format)
-        sigma = torch.dot(u, torch.mv(w, v))
-        return w / sigma
+        """One power iteration (training mode, in place on weight_u / weight_v) and W_orig / sigma:
+        gmt_spectral_norm_fwd, one launch (Discriminator batches its five layers into one call)."""
+        return ops.spectral_norm_weights([self.weight_orig], [self.weight_u], [self.weight_v], self.training, self.eps)[0]
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+        w = self.compute_weight() if weight is None else weight
         if x.is_cuda and x.dim() == 3:          # per-timestep use: weight gradient over L*B rows on the split-K kernel
-            return ops.linear(x, self.compute_weight(), self.bias)
-        return F.linear(x, self.compute_weight(), self.bias)
+            return ops.linear(x, w, self.bias)
+        return F.linear(x, w, self.bias)
 
 
 class _LSTMParams(nn.Module):
@@ -221,6 +215,20 @@ class Discriminator(nn.Module):
                                            SNLinear(H, H // 2), nn.LeakyReLU(0.2), SNLinear(H // 2, 1))
         self.fuse_input_gemm = True
 
+    def spectral_weights(self):
+        """The normalised weights of the five SN-Linears for ONE critic call (one power iteration each in
+        training mode), in module order, from a single launch."""
+        ls = [m for m in list(self.feature_encoder) + list(self.output_layers) if isinstance(m, SNLinear)]
+        return list(ops.spectral_norm_weights([m.weight_orig for m in ls], [m.weight_u for m in ls],
+                                              [m.weight_v for m in ls], self.training, ls[0].eps))
+
+    @staticmethod
+    def run_sequential(seq: nn.Sequential, x: torch.Tensor, weights: List[torch.Tensor]) -> torch.Tensor:
+        """seq(x) with the SN-Linears taking their (precomputed) weights from the front of `weights`."""
+        for m in seq:
+            x = m(x, weights.pop(0)) if isinstance(m, SNLinear) else m(x)
+        return x
+
     def forward_tm(self, pos_tm: torch.Tensor, dts_tm: torch.Tensor, lengths_i32: torch.Tensor,
                    dropout_seed: Optional[int] = None) -> torch.Tensor:
         """Time-major core: pos [L,Bp,2], dts [L,Bp], lengths int32 [Bp] (Bp % 32 == 0) -> [Bp,1].
@@ -228,7 +236,8 @@ class Discriminator(nn.Module):
         two layers it sits between (ops.LSTMLayerFn in_drop / out_drop; mask of layer l = seed + l,
         ops.dropout_keep_mask reproduces it) when the layer shapes allow, else F.dropout."""
         feat = ops.kinematics_tm(pos_tm, dts_tm)
-        x = self.feature_encoder(feat)
+        sn_w = self.spectral_weights()
+        x = self.run_sequential(self.feature_encoder, feat, sn_w)
         H = self.config.discriminator_hidden_dim
         nl = self.config.discriminator_num_layers
         p = float(self.config.lstm_dropout) if self.training else 0.0
@@ -244,7 +253,7 @@ class Discriminator(nn.Module):
             x = h_all
             if l + 1 < nl and p > 0 and not fused:
                 x = F.dropout(x, p, True)
-        return self.output_layers(h_final)
+        return self.run_sequential(self.output_layers, h_final, sn_w)
 
     def forward(self, trajectories: torch.Tensor, dts: torch.Tensor, lengths: torch.Tensor,
                 dropout_seed: Optional[int] = None) -> torch.Tensor:

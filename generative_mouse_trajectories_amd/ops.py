@@ -388,6 +388,66 @@ class LSTMLayerGPFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------
+# spectral normalisation of the critic's Linear weights (csrc/spectral_norm.hip)
+# ----------------------------------------------------------------------------------------
+class SpectralNormFn(torch.autograd.Function):
+    """(training, eps, n, W_1..W_n, u_1..u_n, v_1..v_n) -> (W_1/sigma_1, ..., W_n/sigma_n): what the
+    torch.nn.utils.spectral_norm hooks of RG.py:713-736 compute at every forward, all layers of a critic
+    call in one launch (one more for the backward).  In training mode the u / v buffers advance by one
+    power iteration, in place (they are buffers: autograd never sees them)."""
+
+    @staticmethod
+    def forward(ctx, training: bool, eps: float, n: int, *t):
+        ws, us, vs = t[:n], t[n:2 * n], t[2 * n:3 * n]
+        L_.require_cuda(*ws, *us, *vs)
+        assert 1 <= n <= L_.SN_MAX_LAYERS
+        dev = ws[0].device
+        outs = [torch.empty_like(w, memory_format=torch.contiguous_format) for w in ws]
+        tot = sum(w.shape[0] + w.shape[1] for w in ws)
+        saved = torch.empty(tot + n, device=dev, dtype=torch.float32)      # per layer: u, v; then the n sigmas
+        tab = (L_.SnFwdLayer * n)()
+        offs, o = [], 0
+        for k, (w, u, v) in enumerate(zip(ws, us, vs)):
+            assert w.dim() == 2 and w.is_contiguous() and u.is_contiguous() and v.is_contiguous()
+            assert u.numel() == w.shape[0] and v.numel() == w.shape[1]
+            tab[k] = L_.SnFwdLayer(w.data_ptr(), u.data_ptr(), v.data_ptr(), outs[k].data_ptr(),
+                                   saved.data_ptr() + 4 * (tot + k), saved.data_ptr() + 4 * o, w.shape[0], w.shape[1])
+            offs.append(o)
+            o += w.shape[0] + w.shape[1]
+        L_.call('gmt_spectral_norm_fwd', ctypes_byref_array(tab), n, float(eps), int(bool(training)), L_.stream())
+        ctx.save_for_backward(saved, *ws)
+        ctx.meta = (n, offs, tot)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        saved, *ws = ctx.saved_tensors
+        n, offs, tot = ctx.meta
+        live = [k for k in range(n) if gs[k] is not None and ctx.needs_input_grad[3 + k]]
+        grads: List[Optional[torch.Tensor]] = [None] * n
+        if live:
+            tab = (L_.SnBwdLayer * len(live))()
+            keep = []
+            for q, k in enumerate(live):
+                g = gs[k].contiguous()
+                keep.append(g)
+                grads[k] = torch.empty_like(ws[k], memory_format=torch.contiguous_format)
+                tab[q] = L_.SnBwdLayer(g.data_ptr(), ws[k].data_ptr(), saved.data_ptr() + 4 * offs[k],
+                                       saved.data_ptr() + 4 * (tot + k), grads[k].data_ptr(), ws[k].shape[0], ws[k].shape[1])
+            L_.call('gmt_spectral_norm_bwd', ctypes_byref_array(tab), len(live), L_.stream())
+        return (None, None, None, *grads, *([None] * (2 * n)))
+
+
+def spectral_norm_weights(ws, us, vs, training: bool, eps: float = 1e-12):
+    return SpectralNormFn.apply(training, eps, len(ws), *ws, *us, *vs)
+
+
+def ctypes_byref_array(arr):
+    import ctypes
+    return ctypes.cast(arr, ctypes.c_void_p)
+
+
+# ----------------------------------------------------------------------------------------
 # fused Adam over a flat buffer
 # ----------------------------------------------------------------------------------------
 def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,

@@ -57,9 +57,25 @@ class FlatParams:
         self.total = total
 
     def zero_grad(self):
-        self.grad.zero_()
-        for p, g in zip(self.params, self.views_g):
-            p.grad = g                       # autograd accumulates into the flat buffer in place
+        """Gradients start as None: autograd then hands each parameter its gradient tensor as is
+        instead of launching one `grad += g` kernel per parameter into a zeroed buffer."""
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """After backward: the per-parameter gradients -> the flat buffer (one multi-tensor copy),
+        p.grad re-pointed at its view so that callers, the all-reduce and the fused Adam all see the
+        same memory.  Alignment gaps between segments stay zero from construction."""
+        views, grads = [], []
+        for p, v in zip(self.params, self.views_g):
+            if p.grad is None:
+                v.zero_()                    # unused in this step's graph
+            elif p.grad.data_ptr() != v.data_ptr():
+                views.append(v)
+                grads.append(p.grad)
+            p.grad = v
+        if views:
+            torch._foreach_copy_(views, grads)
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -293,6 +309,7 @@ class Trainer:
                                           self.device, None if alpha is None else alpha.to(self.device))
         total_loss = d_loss + cfg.gradient_penalty_weight * gp
         total_loss.backward()
+        self.d_flat.gather_grads()
         self._allreduce(self.d_flat)
         self.d_optimizer.step()
         vals = torch.stack([d_loss.detach(), gp.detach(), real_score.detach().mean(), fake_score.detach().mean()]).tolist()
@@ -346,6 +363,7 @@ class Trainer:
         direction_loss = ((1 - cosine_sim) * mask).sum() / mask.sum()
         total_loss = g_loss + cfg.endpoint_loss_weight * endpoint_loss + cfg.direction_loss_weight * direction_loss
         total_loss.backward()
+        self.g_flat.gather_grads()
         self._allreduce(self.g_flat)
         self.g_optimizer.step()
         self._g_version += 1

@@ -39,7 +39,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define GMT_ERR_WORKSPACE (-4)    /* caller's workspace is too small                     */
 
 /* ABI version of this header; gmt_version() of the loaded library must match. */
-#define GMT_ABI_VERSION 1
+#define GMT_ABI_VERSION 2
 int gmt_version(void);
 
 /* ---- kinematic features, "mode A" ---------------------------------------------------
@@ -69,6 +69,37 @@ int gmt_telemetry_kinematics_f64(const double* x, const double* y, const double*
 int gmt_telemetry_derived_f64(const double* x, const double* y, const double* raw_dt,
                               const double* total_duration, const double* kin6, const int* lengths,
                               double* out11, long long n_traj, int n_max, hipStream_t stream);
+
+/* ---- spectral normalisation of the critic's Linear weights ---------------------------------
+ * Replaces the torch.nn.utils.spectral_norm hook the reference wraps its five critic Linears in
+ * (RG.py:713, 715, 731, 734, 736; the hook's compute_weight runs at every forward, RG.py:761 / 781).
+ * One workgroup per layer, all layers of a critic call in one launch (n_layers <= GMT_SN_MAX_LAYERS).
+ * power_iterate != 0 (training mode): v <- normalize(W^T u), u <- normalize(W v) written back to
+ * the u / v buffers (eps as F.normalize, 1e-12 in the reference); always: sigma = u . (W v),
+ * w_out = w_orig / sigma.  sigma [1] and uv_saved [out+in] (the u, v the sigma was formed with)
+ * are what gmt_spectral_norm_bwd needs; they may be NULL for an inference call.
+ * Backward: d_w_orig = d_w_sn / sigma - (sum d_w_sn (.) w_orig) / sigma^2 * u v^T. */
+#define GMT_SN_MAX_LAYERS 8
+typedef struct gmt_sn_fwd_layer {
+    const float* w_orig;   /* [out][in] */
+    float* u;              /* [out]  in / out */
+    float* v;              /* [in]   in / out */
+    float* w_out;          /* [out][in] */
+    float* sigma;          /* [1] or NULL */
+    float* uv_saved;       /* [out + in] or NULL */
+    int out_features, in_features;
+} gmt_sn_fwd_layer;
+typedef struct gmt_sn_bwd_layer {
+    const float* d_w_sn;   /* [out][in] */
+    const float* w_orig;
+    const float* uv_saved;
+    const float* sigma;
+    float* d_w_orig;       /* [out][in] */
+    int out_features, in_features;
+} gmt_sn_bwd_layer;
+int gmt_spectral_norm_fwd(const gmt_sn_fwd_layer* layers, int n_layers, float eps, int power_iterate,
+                          hipStream_t stream);
+int gmt_spectral_norm_bwd(const gmt_sn_bwd_layer* layers, int n_layers, hipStream_t stream);
 
 /* ---- fused Adam -----------------------------------------------------------------------
  * Replaces torch.optim.Adam.step for g_optimizer / d_optimizer, RG.py:864-873, 1022, 1110.

@@ -28,7 +28,9 @@ def _worker(rank, world, port, out_dir):
     flat.zero_grad()
     torch.manual_seed(100 + rank)                          # different shard per rank
     x = torch.randn(16, 7)
-    model(x).pow(2).sum().backward()                       # autograd accumulates into the flat buffer
+    model(x).pow(2).sum().backward()
+    flat.gather_grads()                                    # per-parameter gradients -> the flat buffer
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(flat.params, flat.views_g))
     local = flat.grad.clone()
     allreduce_flat_grad(flat, world, None)
     sim = ctypes.CDLL(os.path.join(HERE, 'hostsim', 'libhostsim.so'))
