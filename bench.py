@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 B_LOCAL, T_STEPS, HID, LATENT = 4096, 128, 128, 64
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_BYTES = {('lstm_fwd_fused_I2', 4096): 4.861e9}    # algorithmic: 4.328e9
+PMC_TRAFFIC_BYTES = {('lstm_fwd_fused_I2', 4096): 4.839e9}    # algorithmic: 4.328e9
 
 
 def flops_per_trajectory(T=T_STEPS, Hg=HID, Hd=HID):
@@ -188,7 +188,7 @@ def main():
                 traffic = PMC_TRAFFIC_BYTES.get((name, args.batch))
                 roof = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                        'traffic_unit': 'bytes/launch (profiles/r1_03_pmc_lstm_fwd_I2.txt)' if traffic else None,
+                        'traffic_unit': 'bytes/launch (profiles/r1_06_pmc_lstm_fwd_I2.txt)' if traffic else None,
                         'avg_launch_ms': avg_ms, 'launches': n,
                         'all_kernels_ms_per_step': {k: v[1] / args.steps for k, v in prof.items()}}
         out = {

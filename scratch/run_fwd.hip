@@ -16,7 +16,7 @@ int main()
     CK(hipMalloc(&h, (size_t)L * B * ndir * H * 4));
     CK(hipMalloc(&hf, (size_t)B * ndir * H * 4));
     for (int rep = 0; rep < 2; ++rep) {
-        int rc = gmt_lstm_layer_fwd(x, nullptr, wih, whh, bias, nullptr, gates, c, h, hf, L, B, I, H, ndir, 0.f, 0u, 0);
+        int rc = gmt_lstm_layer_fwd(x, nullptr, wih, whh, bias, nullptr, gates, c, h, hf, L, B, I, H, ndir, 0.1f, 7u, 0);   // inter-layer dropout on, as in the bench
         if (rc) { printf("rc %d\n", rc); return 1; }
         CK(hipDeviceSynchronize());
     }
