@@ -136,6 +136,78 @@ def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False, x_drop: Tupl
     return dW, db
 
 
+# ----------------------------------------------------------------------------------------
+# library GEMMs: which library, per shape
+# ----------------------------------------------------------------------------------------
+_BLAS_CHOICE: dict = {}
+
+
+def _time_mm(a, b, out, reps=3):
+    torch.mm(a, b, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        torch.mm(a, b, out=out)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
+def mm_library(a: torch.Tensor, b: torch.Tensor):
+    """Which BLAS library torch should use for a @ b of this shape: rocBLAS and hipBLASLt each win some
+    of the tall-skinny fp32 shapes of this step (measured on MI355X, [528 384 x 512] x [512 x N]: N = 256
+    rocBLAS 121 vs 113 TFLOP/s, N = 128 hipBLASLt 114 vs 65).  Timed once per (M, N, K) and cached;
+    GMT_BLAS_AUTOTUNE=0 keeps torch's default."""
+    import os
+    key = (a.shape[0], b.shape[1], a.shape[1], a.device.index)
+    lib = _BLAS_CHOICE.get(key)
+    if lib is None:
+        lib = 'default'
+        if os.environ.get('GMT_BLAS_AUTOTUNE', '1') != '0' and a.shape[0] >= 65536:
+            cur = torch.backends.cuda.preferred_blas_library()
+            out = torch.empty(a.shape[0], b.shape[1], device=a.device, dtype=a.dtype)
+            best = None
+            for cand in ('cublaslt', 'cublas'):
+                try:
+                    torch.backends.cuda.preferred_blas_library(cand)
+                    ms = _time_mm(a, b, out)
+                except RuntimeError:
+                    continue
+                if best is None or ms < best[0]:
+                    best = (ms, cand)
+            torch.backends.cuda.preferred_blas_library(cur)
+            if best is not None:
+                lib = best[1]
+        _BLAS_CHOICE[key] = lib
+    return lib
+
+
+class _use_blas:
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        if self.lib != 'default':
+            self.prev = torch.backends.cuda.preferred_blas_library()
+            torch.backends.cuda.preferred_blas_library(self.lib)
+
+    def __exit__(self, *exc):
+        if self.lib != 'default':
+            torch.backends.cuda.preferred_blas_library(self.prev)
+
+
+def dx_from_da(da: torch.Tensor, w_ih: List[torch.Tensor], rows: int) -> torch.Tensor:
+    """dx [rows, I] = sum over directions of da[d] [rows, 4H] @ W_ih[d] (4H axis in the buffers' unit-major
+    order): the one large library GEMM of a layer's backward."""
+    ws = [gate_perm(w.detach()) for w in w_ih]
+    a0 = da[0].view(rows, -1)
+    with _use_blas(mm_library(a0, ws[0])):
+        dx = torch.mm(a0, ws[0])
+        for d in range(1, len(ws)):
+            dx.addmm_(da[d].view(rows, -1), ws[d])
+    return dx
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b over the rows of x [..., I] (the per-timestep Linear layers of the feature
     encoder, RG.py:713-718, applied to L*B rows).  Forward and dx are library GEMMs; the weight and
@@ -145,7 +217,8 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
-        return F.linear(x, w, b)
+        with _use_blas(mm_library(x.reshape(-1, x.shape[-1]), w.detach().t())):
+            return F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
@@ -154,7 +227,10 @@ class LinearFn(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         x2 = x.reshape(-1, x.shape[-1])
-        dx = (dy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            with _use_blas(mm_library(dy2, w)):
+                dx = (dy2 @ w).view(x.shape)
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             dW, db = wgrad(dy2, x2, want_db=ctx.has_b)
@@ -234,10 +310,7 @@ class LSTMLayerFn(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = []
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(da[0].view(L * B, 4 * H), gate_perm(w_ih[0].detach()))
-            for d in range(1, nd):
-                dx.addmm_(da[d].view(L * B, 4 * H), gate_perm(w_ih[d].detach()))
-            dx = dx.view(L, B, I)
+            dx = dx_from_da(da, w_ih, L * B).view(L, B, I)
         need_w = any(ctx.needs_input_grad[6:])
         if need_w:
             grads = _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd, in_drop)
@@ -290,9 +363,7 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
                 L_.ptr(dh_all), L_.ptr(dh_final), None, None, L_.ptr(da), L_.ptr(dct), L_.ptr(dht),
                 L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp')
-        dx = torch.mm(da[0].view(L * B, 4 * H), gate_perm(w_ih[0].detach()))
-        for d in range(1, nd):
-            dx.addmm_(da[d].view(L * B, 4 * H), gate_perm(w_ih[d].detach()))
+        dx = dx_from_da(da, w_ih, L * B)
         ctx.save_for_backward(gates, c_all, lengths, da, dct, dht, *w)
         ctx.dims = (L, B, I, H, nd)
         ctx.has = (dh_all is not None, dh_final is not None)
@@ -379,10 +450,7 @@ class LSTMLayerGPFn(torch.autograd.Function):
                 L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp2')
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(da[0].view(L * B, 4 * H), gate_perm(w_ih[0].detach()))
-            for d in range(1, nd):
-                dx.addmm_(da[d].view(L * B, 4 * H), gate_perm(w_ih[d].detach()))
-            dx = dx.view(L, B, I)
+            dx = dx_from_da(da, w_ih, L * B).view(L, B, I)
         grads = _lstm_weight_grads(da, x.view(L * B, I), h_all, w_hh, L, B, H, nd)
         return (dx, None, *grads)
 
