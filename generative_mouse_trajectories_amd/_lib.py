@@ -10,7 +10,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libgmt_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 ERRORS = {-1: 'bad argument (null pointer / shape / alignment)', -2: 'unsupported configuration',
@@ -28,7 +28,8 @@ class GenFwdArgs(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ('g0', 'w_u_pk', 'w_hh0_pk', 'w_ih1_pk', 'w_hh1_pk', 'bias1', 'w1_pk', 'b1', 'w2',
                                    'b2', 'starts', 'ends', 'init_in', 'target', 'tf_mask', 'out_seq', 'gates0',
                                    'c0_all', 'h0_all', 'gates1', 'c1_all', 'h1_all', 'u_all', 'y_all', 'oraw_all', 'h0d_all')] \
-        + [('T', c_i), ('B', c_i), ('H', c_i), ('dropout_p', c_f), ('seed', ctypes.c_uint)]
+        + [('T', c_i), ('B', c_i), ('H', c_i), ('dropout_p', c_f), ('seed', ctypes.c_uint),
+           ('stop_distance', c_f), ('rows_valid', c_i), ('lengths_out', c_p)]
 
 
 class GenBwdArgs(ctypes.Structure):

@@ -87,6 +87,12 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
         tpx = px; tpy = py;
         in0 = a.init_in[0]; in1 = a.init_in[1]; in2 = a.init_in[2];
     }
+    // sampling with early stop (Generator.generate, RG.py:671-686): a row is done at the first step whose new
+    // position is within stop_distance of its end point; the tile leaves the loop once all its rows are done
+    __shared__ int s_stop;
+    const bool stopping = !TRAIN && a.stop_distance > 0.f;
+    int first_hit = 0, t_exit = a.T;
+    if (tid == 0) s_stop = 0;
     const size_t lane_row = (size_t)row0 + 4 * hi;
     int cur = 0;
     f32x16 acc0[4];
@@ -122,6 +128,9 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
         GMT_PH(0);
         __syncthreads();
         GMT_PH(1);
+        if constexpr (!TRAIN) {
+            if (stopping && s_stop) { t_exit = t; break; }          // uniform: written before the barrier above
+        }
         // ---- S2: layer 0   (acc0 = the time-invariant g0 tile, requested during the previous step's serial tail)
         {
             f32x16 (&acc)[4] = acc0;
@@ -249,11 +258,28 @@ void gen_fwd_kernel(gmt_gen_fwd_args a)
             }
             if (tf) { in0 = t0; in1 = t1; in2 = t2; px = tpx; py = tpy; }
             else { in0 = o0; in1 = o1; in2 = dt; }
+            if constexpr (!TRAIN) {
+                if (stopping) {
+                    const float qx = px - ex, qy = py - ey;
+                    const bool hit = sqrtf(qx * qx + qy * qy) < a.stop_distance || (int)(row0 + tid) >= a.rows_valid;
+                    if (hit && first_hit == 0) first_hit = t + 1;            // RG.py:675-680
+                    if (__all(first_hit != 0) && tid == 0) s_stop = 1;       // the 32 row-owning lanes vote
+                }
+            }
         }
         GMT_PH(6);
         cur ^= 1;
     }
     GMT_PH_DUMP;
+    if constexpr (!TRAIN) {
+        if (stopping) {
+            // steps the tile never ran: zero (the reference keeps generating them until every row of the BATCH
+            // is done; they lie beyond each of these rows' lengths)
+            for (int tt = t_exit; tt < T; ++tt)
+                if (tid < 3 * GMT_TM) a.out_seq[((size_t)tt * B + row0) * 3 + tid] = 0.f;
+            if (tid < GMT_TM && a.lengths_out) a.lengths_out[row0 + tid] = first_hit ? first_hit : T;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------- backward
@@ -556,6 +582,7 @@ extern "C" int gmt_gen_rollout_fwd(const gmt_gen_fwd_args* a, hipStream_t stream
     GMT_CHECK_ARG(a && a->g0 && a->w_u_pk && a->w_hh0_pk && a->w_ih1_pk && a->w_hh1_pk && a->bias1 && a->w1_pk &&
                   a->b1 && a->w2 && a->b2 && a->starts && a->ends && a->init_in && a->out_seq);
     GMT_CHECK_ARG(a->T >= 1 && a->B >= GMT_TM && (a->B % GMT_TM) == 0);
+    GMT_CHECK_ARG(!(a->stop_distance > 0.f) || (!a->gates0 && !a->target && a->rows_valid >= 1 && a->rows_valid <= a->B));
     {   // the saved-activation buffers come all together (training) or not at all (no-grad rollout)
         const int n_saved = !!a->gates0 + !!a->c0_all + !!a->h0_all + !!a->gates1 + !!a->c1_all + !!a->h1_all + !!a->u_all +
                             !!a->y_all + !!a->oraw_all;

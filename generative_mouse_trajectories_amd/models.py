@@ -120,8 +120,9 @@ class Generator(nn.Module):
         return self.condition_encoder(torch.cat([start, end, distance, angle, z], dim=-1))
 
     def _rollout(self, start, end, z, target_tm: Optional[torch.Tensor], tf_mask: Optional[torch.Tensor], T: int,
-                 dropout_seed: Optional[int] = None):
-        """start/end (B,2), z (B,latent), target_tm (T,B,3) -> out (T,B,3); pads B to 32."""
+                 dropout_seed: Optional[int] = None, stop_distance: float = 0.0):
+        """start/end (B,2), z (B,latent), target_tm (T,B,3) -> out (T,B,3); pads B to 32.
+        stop_distance > 0 (sampling): also returns the per-row lengths the kernel found (int32 [B])."""
         L_.require_cuda(start, end, z)
         H = self.config.generator_hidden_dim
         B = start.shape[0]
@@ -142,11 +143,14 @@ class Generator(nn.Module):
         p_drop = float(self.config.lstm_dropout) if self.training else 0.0
         if dropout_seed is None:
             dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
+        lens = torch.empty(Bp, device=start.device, dtype=torch.int32) if stop_distance > 0 else None
         out = ops.GenRolloutFn.apply(g0, w_u, lp.weight_hh_l0, lp.weight_ih_l1, lp.weight_hh_l1, bias1,
                                      self.output_layer[0].weight, self.output_layer[0].bias,
                                      self.output_layer[2].weight, self.output_layer[2].bias,
                                      self.initial_input, s_p, e_p, target_tm, tf_mask, T,
-                                     torch.is_grad_enabled(), p_drop, dropout_seed)
+                                     torch.is_grad_enabled(), p_drop, dropout_seed, float(stop_distance), B, lens)
+        if stop_distance > 0:
+            return out[:, :B], lens[:B]
         return out[:, :B]
 
     def forward(self, start, end, z, target_sequences: Optional[torch.Tensor] = None,
@@ -176,16 +180,27 @@ class Generator(nn.Module):
         return outputs, lengths
 
     @torch.no_grad()
-    def generate(self, start, end, z: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def generate(self, start, end, z: Optional[torch.Tensor] = None, early_exit: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
         """RecurrentGAN.py:606-690: sampling with per-sample early stop at distance < threshold.
-        The rollout runs all max_generation_steps in one launch (rows are independent); the stop
-        step of every row and the common truncation point are then read off the positions."""
+        Default: the rollout runs all max_generation_steps in one launch (rows are independent); the stop
+        step of every row and the common truncation point are then read off the positions - the outputs
+        equal the reference's everywhere, also beyond a row's length.
+        early_exit=True: the kernel tracks the per-row stop step itself and a 32-row tile leaves the time
+        loop as soon as all its rows are done (large sampling jobs); lengths are the same, outputs agree
+        up to each row's length and are zero where a finished tile stopped generating."""
         B = start.shape[0]
         if z is None:
             z = torch.randn(B, self.config.latent_dim, device=start.device)
         was_training = self.training
         self.eval()
         T = self.config.max_generation_steps
+        if early_exit:
+            out, lens = self._rollout(start, end, z, None, None, T, stop_distance=float(self.config.distance_threshold))
+            if was_training:
+                self.train()
+            lengths = lens.long()
+            t_end = int(lengths.max().item())
+            return out.transpose(0, 1)[:, :t_end].contiguous(), lengths
         out = self._rollout(start, end, z, None, None, T).transpose(0, 1)          # (B,T,3)
         if was_training:
             self.train()

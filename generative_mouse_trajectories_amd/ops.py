@@ -548,7 +548,7 @@ class GenRolloutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, g0, w_u, w_hh0, w_ih1, w_hh1, bias1, w1, b1, w2, b2, init_in, starts, ends, target, tf_mask, T,
-                save_for_bwd=True, dropout_p=0.0, seed=0):
+                save_for_bwd=True, dropout_p=0.0, seed=0, stop_distance=0.0, rows_valid=0, lengths_out=None):
         L_.require_cuda(g0)
         B, H4 = g0.shape
         H = H4 // 4
@@ -592,6 +592,9 @@ class GenRolloutFn(torch.autograd.Function):
             a.h0d_all = saved['h0d'].data_ptr()
         a.T, a.B, a.H = T, B, H
         a.dropout_p, a.seed = float(dropout_p), int(seed) & 0xFFFFFFFF
+        if stop_distance > 0:                      # sampling with per-row early stop (no-grad rollout only)
+            assert not need_grad and target is None and lengths_out.dtype == torch.int32 and lengths_out.numel() == B
+            a.stop_distance, a.rows_valid, a.lengths_out = float(stop_distance), int(rows_valid), lengths_out.data_ptr()
         ctx.drop = (float(dropout_p), int(seed) & 0xFFFFFFFF)
         L_.call('gmt_gen_rollout_fwd', ctypes_byref(a), L_.stream(),
                 label='gen_fwd_train' if need_grad else 'gen_fwd_nograd')
@@ -645,7 +648,7 @@ class GenRolloutFn(torch.autograd.Function):
         d_b2 = dov.sum(0)
         d_init = d_in0.sum(0).reshape(ctx.init_shape)
         return (d_g0, d_w_u, d_w_hh0, d_w_ih1, d_w_hh1, d_bias1, d_w1, d_b1, d_w2, d_b2, d_init,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 def ctypes_byref(a):

@@ -39,7 +39,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define GMT_ERR_WORKSPACE (-4)    /* caller's workspace is too small                     */
 
 /* ABI version of this header; gmt_version() of the loaded library must match. */
-#define GMT_ABI_VERSION 2
+#define GMT_ABI_VERSION 3
 int gmt_version(void);
 
 /* ---- kinematic features, "mode A" ---------------------------------------------------
@@ -221,6 +221,13 @@ typedef struct gmt_gen_fwd_args {
     int T, B, H;
     float dropout_p;        /* inter-layer dropout of nn.LSTM(dropout=0.1), RG.py:456; 0 = off (eval / parity) */
     unsigned int seed;      /* mask = f(seed, t, row, unit): regenerated identically by the backward launch */
+    /* sampling with early stop (Generator.generate, RG.py:671-686; no-grad rollout without target only):
+     * stop_distance > 0: row r is done at the first step whose new position lies within stop_distance of
+     * ends[r]; lengths_out[r] = that step count (T if never; rows >= rows_valid, the batch padding, count
+     * as done); a 32-row tile stops once all its rows are done and its remaining out_seq steps are zero. */
+    float stop_distance;
+    int rows_valid;
+    int* lengths_out;       /* [B] or NULL */
 } gmt_gen_fwd_args;
 int gmt_gen_rollout_fwd(const gmt_gen_fwd_args* args, hipStream_t stream);
 

@@ -224,6 +224,31 @@ def test_discriminator_fused_dropout_matches_oracle_with_same_mask(over, B, T):
     H.assert_close(dtsg.grad, gr[-1], 2e-4, 'D gdts with dropout')
 
 
+def test_generate_early_exit_matches_the_full_rollout():
+    """Generator.generate(early_exit=True): the kernel finds each row's stop step itself (RG.py:671-686) and
+    a 32-row tile leaves the time loop when all its rows are done.  Same lengths as the full rollout,
+    identical outputs up to each row's length, zeros where a finished tile stopped."""
+    gmt, cfg, G, D = build(H.MID, 51, 52)
+    cfg.max_generation_steps = 48
+    cfg.distance_threshold = 0.35                 # an untrained generator: make rows stop at assorted steps
+    B = 70                                        # three tiles, the last one with 26 padding rows
+    g = torch.Generator().manual_seed(4)
+    starts = torch.rand(B, 2, generator=g).to(DEV)
+    ends = (starts.cpu() + 0.25 * torch.randn(B, 2, generator=g)).to(DEV)
+    ends[:32] = starts[:32] + 0.01                # tile 0: every row is done after its first step
+    z = torch.randn(B, cfg.latent_dim, generator=g).to(DEV)
+    full, len_full = G.generate(starts, ends, z)
+    fast, len_fast = G.generate(starts, ends, z, early_exit=True)
+    assert torch.equal(len_full.cpu(), len_fast.cpu()), (len_full, len_fast)
+    assert len(set(len_full.tolist())) > 3 and int(len_full[:32].max()) == 1
+    assert full.shape == fast.shape
+    for r in range(B):
+        n = int(len_full[r])
+        assert torch.equal(full[r, :n], fast[r, :n]), r
+    assert torch.all(fast[:32, 1:] == 0)          # tile 0 stopped after one step
+    assert G.training                             # generate() restores the mode it found
+
+
 def test_overlapped_generator_forward_is_the_same_step():
     """Trainer.overlap_g_forward launches the G step's rollout during the D step (second stream).
     With the noise it drew fed to an ordinary trainer, both give the same G step."""
