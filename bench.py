@@ -127,6 +127,7 @@ def main():
     tr = gmt.Trainer(G, D, cfg, dev, log_dir='/tmp/gmt_runs', world_size=world, process_group=pg)
     if force_dist and world == 1:
         tr.world_size = 2                   # take the all-reduce branch (a sum over one rank)
+        tr._enable_overlapped_sync()
         tr.g_optimizer.grad_scale = tr.d_optimizer.grad_scale = 1.0
     tr.epoch = cfg.teacher_forcing_decay_epochs     # steady state: teacher-forcing ratio 0 (fully autoregressive)
     tr.overlap_g_forward = not args.no_overlap      # G-step rollout launched beside the D-step rollout (2 x 128 workgroups)

@@ -129,6 +129,99 @@ def allreduce_flat_grad(flat: FlatParams, world_size: int, group=None) -> None:
         dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=group)
 
 
+class OverlappedGradSync:
+    """Bucketed gradient exchange overlapped with the backward pass: the parameters
+    are cut into consecutive buckets that become final together (a BPTT sweep produces all weight gradients
+    of its layer at once), and as soon as autograd has delivered the last gradient of a bucket its slice of
+    the flat gradient buffer is filled (one multi-tensor copy) and an asynchronous sum all-reduce is started
+    on it - RCCL's own stream, so it runs under the sweeps that are still to come.  finish() waits for the
+    handles before the fused Adam step.  bucket_key(name) labels a parameter; consecutive parameters with
+    the same label form a bucket (the flat buffer follows module.parameters() order, so a bucket is one
+    contiguous slice)."""
+
+    def __init__(self, flat: FlatParams, names: List[str], bucket_key, world_size: int, group=None):
+        self.flat, self.world_size, self.group = flat, world_size, group
+        self.bucket_of: List[int] = []
+        self.buckets: List[Dict] = []
+        last = object()
+        for i, (n, p, o) in enumerate(zip(names, flat.params, flat.offsets)):
+            k = bucket_key(n)
+            if k != last:
+                self.buckets.append({'idx': [], 'lo': o, 'hi': o})
+                last = k
+            b = self.buckets[-1]
+            b['idx'].append(i)
+            b['hi'] = o + (p.numel() + 3) // 4 * 4
+            self.bucket_of.append(len(self.buckets) - 1)
+        self.buckets[-1]['hi'] = flat.total
+        self.enabled = False
+        self.pending: List[int] = []
+        self.launched: List[bool] = []
+        self.works: List = []
+        self._hooks = [p.register_post_accumulate_grad_hook(lambda _p, i=i: self._ready(i))
+                       for i, p in enumerate(flat.params)]
+
+    def begin(self) -> None:
+        """Call right before backward (after zero_grad)."""
+        self.pending = [len(b['idx']) for b in self.buckets]
+        self.launched = [False] * len(self.buckets)
+        self.works = []
+        self.enabled = True
+
+    def _ready(self, i: int) -> None:
+        if not self.enabled:
+            return
+        b = self.bucket_of[i]
+        self.pending[b] -= 1
+        if self.pending[b] == 0 and not self.launched[b]:
+            self._launch(b, async_op=True)
+
+    def _launch(self, b: int, async_op: bool) -> None:
+        import torch.distributed as dist
+        bk = self.buckets[b]
+        views, grads = [], []
+        for i in bk['idx']:
+            p, v = self.flat.params[i], self.flat.views_g[i]
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                views.append(v)
+                grads.append(p.grad)
+            p.grad = v
+        if views:
+            torch._foreach_copy_(views, grads)
+        self.launched[b] = True
+        w = dist.all_reduce(self.flat.grad[bk['lo']:bk['hi']], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op:
+            self.works.append(w)
+
+    def finish(self) -> None:
+        """Call right after backward: buckets autograd never completed (a parameter unused in this step) are
+        exchanged now, then every outstanding all-reduce is waited for (the current stream waits; no host sync
+        with RCCL)."""
+        self.enabled = False
+        for b in range(len(self.buckets)):
+            if not self.launched[b]:
+                self._launch(b, async_op=True)
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+def discriminator_bucket_key(name: str) -> str:
+    """feature_encoder | lstm layer 0 | lstm layer 1 | output_layers: the order the backward finishes them, reversed."""
+    top = name.split('.')[0]
+    if top == 'lstm':
+        return 'lstm' + name.split('_l')[-1][0]
+    return top
+
+
+def generator_bucket_key(name: str) -> str:
+    """(initial_input, condition encoder) | (lstm, output head): the rollout's BPTT launch finishes the second
+    group in one go, the condition encoder follows."""
+    return 'cond' if name.split('.')[0] in ('initial_input', 'condition_encoder') else 'rollout'
+
+
 class _NullWriter:
     def add_scalar(self, *a, **k): pass
     def add_figure(self, *a, **k): pass
@@ -215,6 +308,9 @@ class Trainer:
                                              patience=config.lr_patience, min_lr=config.min_lr)
         self.d_scheduler = ReduceLROnPlateau(self.d_optimizer, mode='min', factor=config.lr_factor,
                                              patience=config.lr_patience, min_lr=config.min_lr)
+        self._g_sync = self._d_sync = None
+        if world_size > 1:
+            self._enable_overlapped_sync()
         self.writer = _make_writer(log_dir)
         self.best_loss = float('inf')
         self.patience_counter = 0
@@ -235,8 +331,23 @@ class Trainer:
         progress = self.epoch / c.teacher_forcing_decay_epochs
         return c.teacher_forcing_start - progress * (c.teacher_forcing_start - c.teacher_forcing_end)
 
-    def _allreduce(self, flat: FlatParams):
-        allreduce_flat_grad(flat, self.world_size, self.process_group)
+    def _enable_overlapped_sync(self) -> None:
+        pick = lambda m, flat: [n for n, p in m.named_parameters() if p.requires_grad]
+        self._g_sync = OverlappedGradSync(self.g_flat, pick(self.generator, self.g_flat), generator_bucket_key,
+                                          self.world_size, self.process_group)
+        self._d_sync = OverlappedGradSync(self.d_flat, pick(self.discriminator, self.d_flat), discriminator_bucket_key,
+                                          self.world_size, self.process_group)
+
+    def _backward_and_sync(self, loss: torch.Tensor, flat: FlatParams, sync: Optional[OverlappedGradSync]) -> None:
+        """backward + gradients into the flat buffer + (data parallel) their sum over the ranks: bucketed
+        all-reduces that start while the backward is still running, or nothing at world size 1."""
+        if sync is not None and self.world_size > 1:
+            sync.begin()
+            loss.backward()
+            sync.finish()
+        else:
+            loss.backward()
+            flat.gather_grads()
 
     def _to_dev(self, batch: Dict):
         d = self.device
@@ -308,9 +419,7 @@ class Trainer:
                                           sel(real_dts_padded), sel(fake_dts_padded), sel(lengths_plus_one),
                                           self.device, None if alpha is None else alpha.to(self.device))
         total_loss = d_loss + cfg.gradient_penalty_weight * gp
-        total_loss.backward()
-        self.d_flat.gather_grads()
-        self._allreduce(self.d_flat)
+        self._backward_and_sync(total_loss, self.d_flat, self._d_sync)
         self.d_optimizer.step()
         vals = torch.stack([d_loss.detach(), gp.detach(), real_score.detach().mean(), fake_score.detach().mean()]).tolist()
         return {'d_loss': vals[0], 'd_gp': vals[1], 'd_real_score': vals[2], 'd_fake_score': vals[3]}
@@ -362,9 +471,7 @@ class Trainer:
         mask = (torch.arange(T, device=self.device).unsqueeze(0) < fake_lengths.unsqueeze(1)).float()
         direction_loss = ((1 - cosine_sim) * mask).sum() / mask.sum()
         total_loss = g_loss + cfg.endpoint_loss_weight * endpoint_loss + cfg.direction_loss_weight * direction_loss
-        total_loss.backward()
-        self.g_flat.gather_grads()
-        self._allreduce(self.g_flat)
+        self._backward_and_sync(total_loss, self.g_flat, self._g_sync)
         self.g_optimizer.step()
         self._g_version += 1
         vals = torch.stack([g_loss.detach(), endpoint_loss.detach(), direction_loss.detach(),

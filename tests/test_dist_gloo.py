@@ -69,3 +69,58 @@ def test_two_rank_gloo_allreduce_and_update(tmp_path):
     for q in ps:
         np.testing.assert_allclose(r0['p'][off:off + q.numel()], q.detach().numpy().reshape(-1), rtol=2e-7, atol=2e-9)
         off += (q.numel() + 3) // 4 * 4
+
+
+def _worker_overlap(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from generative_mouse_trajectories_amd.trainer import FlatParams, OverlappedGradSync
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 6), torch.nn.Tanh(), torch.nn.Linear(6, 5), torch.nn.Tanh(),
+                                torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    for p in model[5].parameters():
+        p.requires_grad_(False)                           # a frozen tail: not part of the flat buffer
+    flat = FlatParams(model)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    sync = OverlappedGradSync(flat, names, lambda n: n.split('.')[0], world, None)
+    assert [len(b['idx']) for b in sync.buckets] == [2, 2, 2]
+    assert sync.buckets[0]['lo'] == 0 and sync.buckets[-1]['hi'] == flat.total
+    assert all(a['hi'] == b['lo'] for a, b in zip(sync.buckets, sync.buckets[1:]))
+    torch.manual_seed(100 + rank)
+    x = torch.randn(16, 7)
+    res = {}
+    for it in range(2):                                   # twice: the bookkeeping resets between steps
+        flat.zero_grad()
+        loss = model(x).pow(2).sum() * (it + 1)
+        local = torch.autograd.grad(loss, flat.params, retain_graph=True)
+        sync.begin()
+        loss.backward()
+        launched_in_backward = list(sync.launched)        # started from the autograd hooks, before finish()
+        sync.finish()
+        assert all(launched_in_backward), launched_in_backward
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(flat.params, flat.views_g))
+        lf = torch.zeros_like(flat.grad)
+        for g, o in zip(local, flat.offsets):
+            lf[o:o + g.numel()] = g.reshape(-1)
+        res[f'local{it}'] = lf.numpy().copy()
+        res[f'summed{it}'] = flat.grad.numpy().copy()
+    # a step in which one bucket gets no gradient at all: finish() still exchanges it (zeros)
+    flat.zero_grad()
+    sync.begin()
+    model[4](torch.randn(4, 5)).sum().backward()
+    assert sync.launched == [False, False, True]
+    sync.finish()
+    assert torch.all(flat.grad[:sync.buckets[2]['lo']] == 0)
+    np.savez(os.path.join(out_dir, f'o{rank}.npz'), **res)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_bucketed_allreduce_overlapped_with_backward(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_overlap, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / 'o0.npz'); r1 = np.load(tmp_path / 'o1.npz')
+    for it in range(2):
+        np.testing.assert_allclose(r0[f'summed{it}'], r0[f'local{it}'] + r1[f'local{it}'], rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(r0[f'summed{it}'], r1[f'summed{it}'])
