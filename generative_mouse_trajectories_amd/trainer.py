@@ -156,6 +156,7 @@ class OverlappedGradSync:
         self.buckets[-1]['hi'] = flat.total
         self.enabled = False
         self.pending: List[int] = []
+        self.next = -1
         self.launched: List[bool] = []
         self.works: List = []
         self._hooks = [p.register_post_accumulate_grad_hook(lambda _p, i=i: self._ready(i))
@@ -165,16 +166,19 @@ class OverlappedGradSync:
         """Call right before backward (after zero_grad)."""
         self.pending = [len(b['idx']) for b in self.buckets]
         self.launched = [False] * len(self.buckets)
+        self.next = len(self.buckets) - 1
         self.works = []
         self.enabled = True
 
     def _ready(self, i: int) -> None:
         if not self.enabled:
             return
-        b = self.bucket_of[i]
-        self.pending[b] -= 1
-        if self.pending[b] == 0 and not self.launched[b]:
-            self._launch(b, async_op=True)
+        self.pending[self.bucket_of[i]] -= 1
+        # Collectives must be issued in the same order on every rank: buckets start strictly last-to-first (the
+        # order the backward pass finishes them); one that completes early waits for its turn.
+        while self.next >= 0 and self.pending[self.next] == 0:
+            self._launch(self.next, async_op=True)
+            self.next -= 1
 
     def _launch(self, b: int, async_op: bool) -> None:
         import torch.distributed as dist
@@ -200,9 +204,9 @@ class OverlappedGradSync:
         exchanged now, then every outstanding all-reduce is waited for (the current stream waits; no host sync
         with RCCL)."""
         self.enabled = False
-        for b in range(len(self.buckets)):
-            if not self.launched[b]:
-                self._launch(b, async_op=True)
+        while self.next >= 0:                            # same last-to-first order as from the hooks
+            self._launch(self.next, async_op=True)
+            self.next -= 1
         for w in self.works:
             w.wait()
         self.works = []

@@ -113,6 +113,14 @@ def _worker_overlap(rank, world, port, out_dir):
     assert sync.launched == [False, False, True]
     sync.finish()
     assert torch.all(flat.grad[:sync.buckets[2]['lo']] == 0)
+    # a bucket that completes out of turn waits: only the FIRST module gets gradients -> nothing starts in backward
+    flat.zero_grad()
+    sync.begin()
+    model[0](torch.randn(4, 7)).sum().backward()
+    assert sync.launched == [False, False, False] and sync.pending == [0, 2, 2]
+    sync.finish()
+    assert all(sync.launched)
+    assert torch.all(flat.grad[sync.buckets[1]['lo']:] == 0)
     np.savez(os.path.join(out_dir, f'o{rank}.npz'), **res)
     dist.destroy_process_group()
 
