@@ -8,7 +8,10 @@
 namespace {
 
 constexpr int KB = 256;        // trajectories per block
-constexpr int KCH = 8;         // consecutive timesteps per block
+#ifndef GMT_KIN_KCH
+#define GMT_KIN_KCH 8
+#endif
+constexpr int KCH = GMT_KIN_KCH;  // consecutive timesteps per block
 
 // Block = 256 consecutive trajectories x KCH consecutive timesteps.  A thread keeps its trajectory and walks t,
 // so the 3-step look-back (look-ahead in the backward) re-reads lines this CU fetched one trip earlier instead
