@@ -108,3 +108,171 @@ def test_telemetry_recompute_at_sampling_scale():
             assert np.abs(kin[j, :m, r] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1.0), (k, r)
         ref = o['curvature']
         assert np.abs(kin[5, :m, r] - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-300), ('curvature', r)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Backward sweeps, BPTT and the second-order (gradient penalty) sweep at the bench LENGTH (T = 128, L = 129,
+# H = 128) against the CPU oracle in fp64, on row slices the oracle finishes in seconds (RG.py:790-842,
+# 913-1118).  The bar is BASELINE's 1e-4 (3e-4 for the second-order path, as at the toy length), or four times
+# the fp32 oracle's own distance from the fp64 oracle where that is larger: an untrained critic's outputs are
+# small differences of large terms, so plain fp32 arithmetic is itself further than 1e-4 from exact there.
+# ----------------------------------------------------------------------------------------------------------
+def _ragged_batch(Bs, seed, dtype=torch.float32, end_offset=0.0):
+    rng = np.random.default_rng(seed)
+    lengths = rng.integers(T // 2, T + 1, Bs)
+    lengths[:2] = T
+    b = H.batch_t(Bs, T, seed, lengths.tolist(), dtype)
+    if end_offset:
+        b['ends'] = b['ends'] + end_offset        # keeps atan2(end - pos) well conditioned under teacher forcing
+    return b
+
+
+def _tol(base, a32, a64):
+    return max(base, 4.0 * H.relerr(a32, a64))
+
+
+def _named_grads(out, P, extra=()):
+    keys = list(P.keys())
+    g = torch.autograd.grad(out, [P[k] for k in keys] + list(extra), allow_unused=True)
+    gd = {k: (torch.zeros_like(P[k]) if v is None else v) for k, v in zip(keys, g[:len(keys)])}
+    return gd, g[len(keys):]
+
+
+def test_discriminator_backward_at_bench_length_vs_oracle():
+    """(a) D parameter and input gradients at L = 129: lstm_bwd (both layers, both directions, ragged lengths),
+    gmt_wgrad, the dx contractions, the feature encoder and the kinematics backward."""
+    gmt, cfg, G, D = build(H.MID, 61, 62)
+    Bs = 64
+    b = _ragged_batch(Bs, 63)
+    traj = gmt.trajectory_to_absolute(b['starts'], b['sequences'][:, :, :2])
+    dts = torch.nn.functional.pad(b['sequences'][:, :, 2], (1, 0), value=0.001)
+    lp1 = b['lengths'] + 1
+    w = torch.randn(Bs, 1, generator=torch.Generator().manual_seed(64))
+    trajg, dtsg = traj.to(DEV).requires_grad_(True), dts.to(DEV).requires_grad_(True)
+    D.zero_grad()
+    score = D(trajg, dtsg, lp1.to(DEV))
+    (score * w.to(DEV)).sum().backward()
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        _, _, Pd, Bd = H.oracle_models(H.MID, 61, 62, dt)
+        P = {k: v.requires_grad_(True) for k, v in Pd.items()}
+        tr, dr = traj.to(dt).requires_grad_(True), dts.to(dt).requires_grad_(True)
+        s = O.discriminator_forward(P, Bd, tr, dr, lp1, training=True)
+        gd, (gt, gdt) = _named_grads((s * w.to(dt)).sum(), P, (tr, dr))
+        res[dt] = (s.detach(), gd, gt, gdt)
+    s32, g32, gt32, gd32 = res[torch.float32]
+    s64, g64, gt64, gd64 = res[torch.float64]
+    H.assert_close(score, s64, _tol(1e-4, s32, s64), 'D score at L=129')
+    for k, p in D.named_parameters():
+        H.assert_close(p.grad, g64[k], _tol(1e-4, g32[k], g64[k]), f'D grad {k} at L=129')
+    H.assert_close(trajg.grad, gt64, _tol(1e-4, gt32, gt64), 'D gtraj at L=129')
+    H.assert_close(dtsg.grad, gd64, _tol(1e-4, gd32, gd64), 'D gdts at L=129')
+
+
+def test_generator_bptt_at_bench_length_vs_oracle():
+    """(b) generator BPTT parameter gradients at T = 128 with a mixed teacher-forcing mask and the fused
+    inter-layer dropout mask (gen_fwd_kernel<TRAIN>, gen_bwd_kernel, the wgrad contractions over T*B rows)."""
+    from generative_mouse_trajectories_amd import ops
+    gmt, cfg, G, D = build(H.MID, 71, 72)
+    cfg.lstm_dropout = 0.1
+    seed = 4242
+    Bs = 64
+    b = _ragged_batch(Bs, 73, end_offset=0.07)
+    z = torch.randn(Bs, cfg.latent_dim, generator=torch.Generator().manual_seed(74))
+    rng = np.random.default_rng(75)
+    mask_tf = [bool(v) for v in (rng.random(T) < 0.3)]
+    assert any(mask_tf) and not all(mask_tf)
+    w = torch.randn(Bs, T, 3, generator=torch.Generator().manual_seed(76))
+    bd = {k: v.to(DEV) for k, v in b.items()}
+    G.zero_grad()
+    seq, _ = G(bd['starts'], bd['ends'], z.to(DEV), target_sequences=bd['sequences'], target_lengths=bd['lengths'],
+               tf_mask=mask_tf, dropout_seed=seed)
+    (seq * w.to(DEV)).sum().backward()
+    dm = ops.dropout_keep_mask(T, ops.pad_rows(Bs), cfg.generator_hidden_dim, cfg.lstm_dropout, seed)[:, :Bs]
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        P = {k: v.detach().cpu().to(dt).requires_grad_(True) for k, v in G.state_dict().items()}
+        ref = O.generator_forward(P, b['starts'].to(dt), b['ends'].to(dt), z.to(dt), b['sequences'].to(dt), mask_tf,
+                                  dropout_mask=dm.to(dt))
+        gd, _ = _named_grads((ref * w.to(dt)).sum(), P)
+        res[dt] = (ref.detach(), gd)
+    r32, g32 = res[torch.float32]
+    r64, g64 = res[torch.float64]
+    H.assert_close(seq, r64, _tol(1e-4, r32, r64), 'G rollout (TF mix + dropout) at T=128')
+    for k, p in G.named_parameters():
+        H.assert_close(p.grad, g64[k], _tol(1e-4, g32[k], g64[k]), f'G BPTT grad {k} at T=128')
+
+
+def test_gradient_penalty_at_bench_length_vs_oracle():
+    """(c) compute_gradient_penalty value and D-parameter gradients at L = 129: the second-order sweep
+    (lstm_bwd2_kernel) and the EXTRA / out-of-place backward variants over 129 steps, ragged lengths."""
+    gmt, cfg, G, D = build(H.MID, 81, 82)
+    Bs = 32
+    b = _ragged_batch(Bs, 83)
+    g = torch.Generator().manual_seed(84)
+    real = gmt.trajectory_to_absolute(b['starts'], b['sequences'][:, :, :2])
+    fake = real + 0.02 * torch.randn(real.shape, generator=g)
+    rdts = torch.nn.functional.pad(b['sequences'][:, :, 2], (1, 0), value=0.001)
+    fdts = rdts * (0.75 + 0.5 * torch.rand(rdts.shape, generator=g))
+    alpha = torch.rand(Bs, generator=g)
+    lp1 = b['lengths'] + 1
+    D.zero_grad()
+    gp = gmt.compute_gradient_penalty(D, real.to(DEV), fake.to(DEV), rdts.to(DEV), fdts.to(DEV), lp1.to(DEV),
+                                      torch.device(DEV), alpha=alpha.to(DEV))
+    gp.backward()
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        _, _, Pd, Bd = H.oracle_models(H.MID, 81, 82, dt)
+        P = {k: v.requires_grad_(True) for k, v in Pd.items()}
+        v, inner = O.gradient_penalty(P, Bd, real.to(dt), fake.to(dt), rdts.to(dt), fdts.to(dt), lp1, alpha.to(dt),
+                                      return_grads=True, training=True)
+        gd, _ = _named_grads(v, P)
+        res[dt] = (v.detach(), gd)
+    v32, g32 = res[torch.float32]
+    v64, g64 = res[torch.float64]
+    tol_v = _tol(1e-4, v32, v64)
+    assert abs(gp.item() - float(v64)) <= tol_v * abs(float(v64)), (gp.item(), float(v64), float(v32))
+    for k, p in D.named_parameters():
+        gr = p.grad if p.grad is not None else torch.zeros_like(p)
+        H.assert_close(gr, g64[k], _tol(3e-4, g32[k], g64[k]), f'GP grad {k} at L=129')
+
+
+def test_train_steps_at_bench_length_vs_oracle():
+    """(d) one full D step (with the gradient penalty) and one G step of the Trainer at T = 128: every returned
+    metric and every parameter gradient against the oracle's step functions (RG.py:913-1118)."""
+    gmt, cfg, G, D = build(H.MID, 91, 92)
+    Bs = 32
+    tr = gmt.Trainer(G, D, cfg, torch.device(DEV), '/tmp/runs_gpu_full')
+    tr.epoch = 30                                           # teacher-forcing ratio 0.7: the mask below stands for its coins
+    b = _ragged_batch(Bs, 93, end_offset=0.05)
+    g = torch.Generator().manual_seed(94)
+    nb = -(-Bs // 4)
+    noise = {'z': torch.randn(Bs, 64, generator=g), 'gp_idx': torch.randperm(Bs, generator=g), 'alpha': torch.rand(nb, generator=g)}
+    zg = torch.randn(Bs, 64, generator=g)
+    mask_tf = [bool(v) for v in (np.random.default_rng(95).random(T) < 0.7)]
+    m_d = tr.train_discriminator_step(b, dict(noise))
+    gd_gpu = {k: p.grad.detach().clone() for k, p in D.named_parameters()}
+    m_g = tr.train_generator_step(b, {'z': zg, 'tf_mask': mask_tf})
+    gg_gpu = {k: p.grad.detach().clone() for k, p in G.named_parameters()}
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        oc, Pg, Pd, Bd = H.oracle_models(H.MID, 91, 92, dt)
+        bb = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in b.items()}
+        nz = {'z': noise['z'].to(dt), 'gp_idx': noise['gp_idx'], 'alpha': noise['alpha'].to(dt)}
+        md, gd, _ = O.discriminator_step(Pg, Pd, Bd, {}, bb, nz, oc, 0)
+        mg, gg, _ = O.generator_step(Pg, Pd, Bd, {}, bb, {'z': zg.to(dt)}, oc, mask_tf, tr.get_teacher_forcing_ratio())
+        res[dt] = (md, gd, mg, gg)
+    md32, gd32, mg32, gg32 = res[torch.float32]
+    md64, gd64, mg64, gg64 = res[torch.float64]
+    for got, r32, r64 in ((m_d, md32, md64), (m_g, mg32, mg64)):
+        for k, v in r64.items():
+            tol = max(1e-4, 4.0 * abs(r32[k] - v) / max(abs(v), 1e-3))
+            assert abs(got[k] - v) <= tol * max(abs(v), 1e-3), (k, got[k], v, r32[k])
+    for k, gr in gd_gpu.items():
+        ref = gd64[k] if gd64[k] is not None else torch.zeros_like(gr).cpu()
+        r32 = gd32[k] if gd32[k] is not None else torch.zeros_like(ref)
+        H.assert_close(gr, ref, _tol(3e-4, r32, ref), f'D step grad {k} at T=128')
+    for k, gr in gg_gpu.items():
+        ref = gg64[k] if gg64[k] is not None else torch.zeros_like(gr).cpu()
+        r32 = gg32[k] if gg32[k] is not None else torch.zeros_like(ref)
+        H.assert_close(gr, ref, _tol(1e-4, r32, ref), f'G step grad {k} at T=128')
