@@ -12,6 +12,13 @@
 //   * the column sums of dA (= bias gradient) are accumulated by the staging threads for free.
 #include "lstm_tile.h"
 #include <cstdlib>
+#include <mutex>
+
+// Scratch of gmt_wgrad_noalloc (include/gmt_hip.h): the split-K slab buffer that gmt_wgrad takes from its
+// caller as `workspace`, as one file-scope device array per GPU (65 MiB, held until the process ends).  In
+// host code the NAME of this array is only a stand-in: its device address comes from hipGetSymbolAddress,
+// once per device, and that pointer is what the kernels and every other HIP call are given.
+static __device__ __align__(256) float gmt_wgrad_scratch[GMT_WGRAD_NOALLOC_MAX_FLOATS];
 
 namespace {
 
@@ -274,6 +281,50 @@ extern "C" int gmt_wgrad_workspace_floats(int N, int I, long long R, int* ksplit
     if (ksplit_out) *ksplit_out = ks;
     if (floats_out) *floats_out = (long long)ks * N * I + (long long)ks * N;
     return GMT_OK;
+}
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+float* g_scratch_ptr[kMaxDevices];       // per device: each GPU holds its own copy of the array at its own address
+
+// device address of gmt_wgrad_scratch on the CURRENT device (looked up once per device)
+int wgrad_scratch_ptr(float** out)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return GMT_ERR_HIP;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(gmt_wgrad_scratch)) != hipSuccess || !p) return GMT_ERR_HIP;
+        g_scratch_ptr[dev] = static_cast<float*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return GMT_OK;
+}
+}  // namespace
+
+extern "C" int gmt_wgrad_noalloc_init(void)
+{
+    float* p = nullptr;
+    return wgrad_scratch_ptr(&p);
+}
+
+extern "C" int gmt_wgrad_noalloc(const float* dA, long long lda, const float* X, long long ldx, long long R, int N, int I,
+                                 float* dW, float* db, int accumulate, float x_dropout_p, unsigned x_dropout_seed,
+                                 hipStream_t stream)
+{
+    int ks = 0; long long need = 0;
+    const int rc = gmt_wgrad_workspace_floats(N, I, R, &ks, &need);
+    if (rc != GMT_OK) return rc;
+    if (need > (long long)GMT_WGRAD_NOALLOC_MAX_FLOATS) return GMT_ERR_WORKSPACE;   // beyond the static scratch: use gmt_wgrad
+    float* ws = nullptr;
+    const int rp = wgrad_scratch_ptr(&ws);
+    if (rp != GMT_OK) return rp;
+    // every slab element the reduction reads is written by this call's wgrad_kernel launch first, so the
+    // previous call's contents never show and nothing has to be cleared
+    return gmt_wgrad(dA, lda, X, ldx, R, N, I, dW, db, accumulate, ws, (long long)GMT_WGRAD_NOALLOC_MAX_FLOATS,
+                     x_dropout_p, x_dropout_seed, stream);
 }
 
 extern "C" int gmt_wgrad(const float* dA, long long lda, const float* X, long long ldx, long long R, int N, int I,

@@ -39,7 +39,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define GMT_ERR_WORKSPACE (-4)    /* caller's workspace is too small                     */
 
 /* ABI version of this header; gmt_version() of the loaded library must match. */
-#define GMT_ABI_VERSION 3
+#define GMT_ABI_VERSION 4
 int gmt_version(void);
 
 /* ---- kinematic features, "mode A" ---------------------------------------------------
@@ -187,6 +187,23 @@ int gmt_wgrad_workspace_floats(int N, int I, long long R, int* ksplit_out, long 
 int gmt_wgrad(const float* dA, long long lda, const float* X, long long ldx, long long R, int N, int I,
               float* dW, float* db, int accumulate, float* workspace, long long workspace_floats,
               float x_dropout_p, unsigned x_dropout_seed, hipStream_t stream);
+
+/* gmt_wgrad_noalloc: gmt_wgrad for callers that cannot allocate - code under HIP graph capture, tight
+ * serving / training loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference (which
+ * never allocates device memory itself).  Same kernels and same results as gmt_wgrad bit for bit; the split-K
+ * slab buffer is a static device array inside the library (GMT_WGRAD_NOALLOC_MAX_FLOATS floats = 65 MiB on
+ * each GPU the library runs on, held until the process ends) instead of a caller workspace.  Calls no
+ * hipMalloc / hipFree or any allocating routine.  Shapes whose gmt_wgrad_workspace_floats exceeds the maximum
+ * return GMT_ERR_WORKSPACE.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU
+ * (two streams, two threads) race - serialise them.  Nothing needs clearing between calls (every slab element
+ * read is written first by the same call).  gmt_wgrad_noalloc_init looks the array's device address up for
+ * the current device (hipGetSymbolAddress, once per device; otherwise done by the first call on that device):
+ * call it once per device before capturing a graph. */
+#define GMT_WGRAD_NOALLOC_MAX_FLOATS 17039360LL
+int gmt_wgrad_noalloc_init(void);
+int gmt_wgrad_noalloc(const float* dA, long long lda, const float* X, long long ldx, long long R, int N, int I,
+                      float* dW, float* db, int accumulate, float x_dropout_p, unsigned x_dropout_seed,
+                      hipStream_t stream);
 
 /* ---- persistent generator rollout -----------------------------------------------------------
  * Replaces the autoregressive loop of Generator.forward, RG.py:508-604 (dynamic features
