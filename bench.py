@@ -158,7 +158,7 @@ def main():
     prof = _lib.profile_stop()
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

@@ -110,14 +110,55 @@ class FusedAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         # re-home loaded moments into the flat buffers
+        # (a parameter that never received a gradient has no entry in a torch.optim.Adam checkpoint: zero moments.
+        # One step count serves the whole flat buffer: the largest one found - in the reference every parameter
+        # of a model gets a gradient at every step, so they all agree.)
         steps = [int(st['step']) for st in self.state.values() if 'step' in st]
         self.step_count = max(steps) if steps else 0
         for p, o in zip(self.flat.params, self.flat.offsets):
             st = self.state[p]
             for key, buf in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq)):
                 view = buf[o:o + p.numel()].view_as(p)
-                view.copy_(st[key])
+                if key in st:
+                    view.copy_(st[key])
+                else:
+                    view.zero_()
                 st[key] = view
+            st['step'] = torch.tensor(float(self.step_count))
+
+
+def _host_backend(group=None) -> bool:
+    """True when the process group's collectives run on the host (gloo: the CPU tests and the rehearsal of N ranks
+    on one GPU).  ProcessGroupGloo does accept device tensors, staging them through pinned memory on high-priority
+    pool streams of its own - and with a deep queue of persistent kernels ahead of it that staging never gets its
+    turn (measured on MI355X, two ranks sharing the card at B = 4096: the GPU sits at 100 % busy and the event
+    recorded before the FIRST collective is never reached, on either rank, while the same step with the collective
+    on an explicit host copy runs at full speed; tools/two_rank_diag.py).  So device tensors
+    are never handed to gloo: all_reduce_sum / broadcast_ stage them through the host on the caller's own stream."""
+    import torch.distributed as dist
+    return dist.get_backend(group) == 'gloo'
+
+
+def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
+    """Sum all-reduce of `t` in place: RCCL on the device buffer (asynchronous if asked), or - host backend - on a
+    host copy (synchronous; returns None)."""
+    import torch.distributed as dist
+    if t.is_cuda and _host_backend(group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def broadcast_(t: torch.Tensor, src: int, group=None) -> None:
+    import torch.distributed as dist
+    if t.is_cuda and _host_backend(group):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
 
 
 def allreduce_flat_grad(flat: FlatParams, world_size: int, group=None) -> None:
@@ -125,8 +166,7 @@ def allreduce_flat_grad(flat: FlatParams, world_size: int, group=None) -> None:
     the CPU tests) of the model's flat gradient buffer; the 1/world_size factor is applied by
     the fused Adam kernel (grad_scale)."""
     if world_size > 1:
-        import torch.distributed as dist
-        dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=group)
+        all_reduce_sum(flat.grad, group)
 
 
 class OverlappedGradSync:
@@ -155,6 +195,7 @@ class OverlappedGradSync:
             self.bucket_of.append(len(self.buckets) - 1)
         self.buckets[-1]['hi'] = flat.total
         self.enabled = False
+        self.host_backend = flat.grad.is_cuda and _host_backend(group)
         self.pending: List[int] = []
         self.next = -1
         self.launched: List[bool] = []
@@ -195,6 +236,8 @@ class OverlappedGradSync:
         if views:
             torch._foreach_copy_(views, grads)
         self.launched[b] = True
+        if self.host_backend:
+            return                       # exchanged by finish(): one host-staged all-reduce of the whole buffer
         w = dist.all_reduce(self.flat.grad[bk['lo']:bk['hi']], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:
             self.works.append(w)
@@ -210,6 +253,8 @@ class OverlappedGradSync:
         for w in self.works:
             w.wait()
         self.works = []
+        if self.host_backend:
+            all_reduce_sum(self.flat.grad, self.group)
 
 
 def discriminator_bucket_key(name: str) -> str:
@@ -222,6 +267,13 @@ def generator_bucket_key(name: str) -> str:
     """(initial_input, condition encoder) | (lstm, output head): the rollout's BPTT launch finishes the second
     group in one go, the condition encoder follows."""
     return 'cond' if name.split('.')[0] in ('initial_input', 'condition_encoder') else 'rollout'
+
+
+def dp_tf_coins(tf_seed: int, g_step: int, T: int, tf_ratio: float) -> List[bool]:
+    """Teacher-forcing coins of generator step number g_step under data parallelism: a pure function of
+    (tf_seed, g_step), so every rank decides alike; a shorter T is a prefix of a longer one."""
+    g = torch.Generator().manual_seed((int(tf_seed) * 1000003 + int(g_step)) & 0x7FFFFFFF)
+    return [bool(v) for v in (torch.rand(T, generator=g) < tf_ratio).tolist()]
 
 
 class _NullWriter:
@@ -311,6 +363,11 @@ class Trainer:
         self.d_scheduler = ReduceLROnPlateau(self.d_optimizer, mode='min', factor=config.lr_factor,
                                              patience=config.lr_patience, min_lr=config.min_lr)
         self._g_sync = self._d_sync = None
+        # data parallel: the per-step teacher-forcing coins are host decisions that every rank must take alike
+        # (the rollout kernels of all ranks follow the same path): they come from this
+        # generator, re-seeded per generator step, never from the rank's own global RNG
+        self.tf_seed = 0
+        self._g_step = 0
         if world_size > 1:
             self._enable_overlapped_sync()
         self.writer = _make_writer(log_dir)
@@ -324,6 +381,7 @@ class Trainer:
         self._side = None
         self._spec = None
         self._g_version = 0
+        self.sync_replicas()
 
     # ---- helpers ---------------------------------------------------------------------
     def get_teacher_forcing_ratio(self) -> float:
@@ -339,6 +397,31 @@ class Trainer:
                                           self.world_size, self.process_group)
         self._d_sync = OverlappedGradSync(self.d_flat, pick(self.discriminator, self.d_flat), discriminator_bucket_key,
                                           self.world_size, self.process_group)
+
+    def sync_replicas(self) -> None:
+        """Data parallel: every rank takes rank 0's parameters, Adam moments and spectral-norm buffers, so
+        replicas are identical whatever RNG state each process built its models from (construction, and again
+        after load_checkpoint)."""
+        if self.world_size <= 1:
+            return
+        import torch.distributed as dist
+        src = dist.get_global_rank(self.process_group, 0) if self.process_group is not None else 0
+        steps = torch.tensor([self.g_optimizer.step_count, self.d_optimizer.step_count, self.d_step, self._g_step],
+                             device=self.device, dtype=torch.int64)
+        ts = [self.g_flat.flat, self.d_flat.flat, self.g_optimizer.exp_avg, self.g_optimizer.exp_avg_sq,
+              self.d_optimizer.exp_avg, self.d_optimizer.exp_avg_sq, steps]
+        ts += [b for m in (self.generator, self.discriminator) for b in m.buffers()]
+        for t_ in ts:
+            broadcast_(t_, src, self.process_group)
+        self.g_optimizer.step_count, self.d_optimizer.step_count, self.d_step, self._g_step = (int(v) for v in steps.tolist())
+
+    def _tf_coins(self, T: int, tf_ratio: float) -> List[bool]:
+        """The per-step teacher-forcing coins of RG.py:588.  One process: torch.rand(1) per step from the global
+        CPU generator, exactly like the reference.  Data parallel: from a generator seeded by (tf_seed, index of
+        this generator step) - the same sequence on every rank (ranks whose batches differ in T share the prefix)."""
+        if self.world_size <= 1:
+            return [torch.rand(1).item() < tf_ratio for _ in range(T)]
+        return dp_tf_coins(self.tf_seed, self._g_step, T, tf_ratio)
 
     def _backward_and_sync(self, loss: torch.Tensor, flat: FlatParams, sync: Optional[OverlappedGradSync]) -> None:
         """backward + gradients into the flat buffer + (data parallel) their sum over the ranks: bucketed
@@ -373,7 +456,7 @@ class Trainer:
         T = sequences.shape[1]
         tf_ratio = self.get_teacher_forcing_ratio()
         if tf_mask is None:
-            tf_mask = [torch.rand(1).item() < tf_ratio for _ in range(T)]
+            tf_mask = self._tf_coins(T, tf_ratio)
         tf_mask = [bool(b) for b in tf_mask]
         with torch.cuda.stream(self._side):
             z = torch.randn(sequences.shape[0], self.config.latent_dim, device=self.device)
@@ -449,9 +532,12 @@ class Trainer:
         else:
             z = noise.get('z')
             z = torch.randn(batch_size, cfg.latent_dim, device=self.device) if z is None else z.to(self.device)
+            if tf_mask is None and self.world_size > 1:
+                tf_mask = self._tf_coins(T, tf_ratio)
             fake_sequences, fake_lengths = self.generator(starts, ends, z, target_sequences=sequences,
                                                           target_lengths=lengths, teacher_forcing_ratio=tf_ratio,
                                                           tf_mask=tf_mask)
+        self._g_step += 1
         fake_deltas = fake_sequences[:, :, :2]
         fake_trajectories = trajectory_to_absolute(starts, fake_deltas)
         fake_dts_padded = F.pad(fake_sequences[:, :, 2], (1, 0), value=0.001)
@@ -474,8 +560,19 @@ class Trainer:
         movement_directions = fake_deltas / movement_norms
         cosine_sim = (movement_directions * target_direction.unsqueeze(1)).sum(dim=-1)
         mask = (torch.arange(T, device=self.device).unsqueeze(0) < fake_lengths.unsqueeze(1)).float()
-        direction_loss = ((1 - cosine_sim) * mask).sum() / mask.sum()
-        total_loss = g_loss + cfg.endpoint_loss_weight * endpoint_loss + cfg.direction_loss_weight * direction_loss
+        dir_num, dir_den = ((1 - cosine_sim) * mask).sum(), mask.sum()
+        direction_loss = dir_num / dir_den
+        dir_for_grad = direction_loss
+        if self.world_size > 1:
+            # RG.py:1095 divides by the mask sum of the WHOLE batch: with ragged lengths the shards' mask sums differ,
+            # so numerator and denominator are summed over the ranks (one 2-element all-reduce) and the local term is
+            # scaled so that the 1/world of the gradient average gives d(sum num / sum den) exactly
+            import torch.distributed as dist
+            nd = torch.stack([dir_num.detach(), dir_den])
+            all_reduce_sum(nd, self.process_group)
+            direction_loss = nd[0] / nd[1]
+            dir_for_grad = dir_num * (float(dist.get_world_size(self.process_group)) / nd[1])
+        total_loss = g_loss + cfg.endpoint_loss_weight * endpoint_loss + cfg.direction_loss_weight * dir_for_grad
         self._backward_and_sync(total_loss, self.g_flat, self._g_sync)
         self.g_optimizer.step()
         self._g_version += 1
@@ -502,6 +599,26 @@ class Trainer:
         avg = {k: float(np.mean(v)) for k, v in epoch_metrics.items() if v}
         avg['teacher_forcing_ratio'] = self.get_teacher_forcing_ratio()
         return avg
+
+    def _rank(self) -> int:
+        if self.world_size <= 1:
+            return 0
+        import torch.distributed as dist
+        return dist.get_rank(self.process_group)
+
+    def _reduce_metrics(self, metrics: Dict[str, float]) -> Dict[str, float]:
+        """Data parallel: the epoch metrics drive ReduceLROnPlateau, the best-loss test and early stopping, so every
+        rank must see the same numbers (else learning rates diverge and one rank leaves the loop while the others
+        wait in an all-reduce): their mean over the ranks, one small all-reduce per epoch."""
+        if self.world_size <= 1:
+            return metrics
+        import torch.distributed as dist
+        keys = sorted(metrics)
+        t_ = torch.tensor([metrics[k] for k in keys], dtype=torch.float64)
+        if not _host_backend(self.process_group):
+            t_ = t_.to(self.device)
+        dist.all_reduce(t_, op=dist.ReduceOp.SUM, group=self.process_group)
+        return {k: float(v) / self.world_size for k, v in zip(keys, t_.tolist())}
 
     def log_metrics(self, metrics: Dict[str, float], step: int) -> None:
         for name, value in metrics.items():
@@ -534,6 +651,7 @@ class Trainer:
         self.g_optimizer.load_state_dict(checkpoint['g_optimizer_state_dict'])
         self.d_optimizer.load_state_dict(checkpoint['d_optimizer_state_dict'])
         self.best_loss = checkpoint.get('best_loss', float('inf'))
+        self.sync_replicas()
         print(f'Loaded checkpoint from epoch {self.epoch}')
 
     def train(self, dataloader, num_epochs: int, checkpoint_dir: str = 'checkpoints') -> None:
@@ -543,7 +661,7 @@ class Trainer:
         print(f'Batch size: {self.config.batch_size}')
         for epoch in range(self.epoch, num_epochs):
             self.epoch = epoch
-            metrics = self.train_epoch(dataloader)
+            metrics = self._reduce_metrics(self.train_epoch(dataloader))
             self.log_metrics(metrics, epoch)
             if epoch % 10 == 0:
                 self.log_trajectories(dataloader, epoch)
@@ -558,7 +676,11 @@ class Trainer:
                 self.patience_counter += 1
                 is_best = False
             if epoch % 10 == 0 or is_best:
-                self.save_checkpoint(os.path.join(checkpoint_dir, f'checkpoint_epoch_{epoch}.pt'), is_best)
+                if self._rank() == 0:
+                    self.save_checkpoint(os.path.join(checkpoint_dir, f'checkpoint_epoch_{epoch}.pt'), is_best)
+                if self.world_size > 1:
+                    import torch.distributed as dist
+                    dist.barrier(group=self.process_group)       # nobody runs ahead of the file being complete
             print(f"Epoch {epoch}/{num_epochs} | D Loss: {metrics['d_loss']:.4f} | G Loss: {metrics['g_loss']:.4f} | "
                   f"Endpoint: {metrics['g_endpoint_loss']:.4f} | TF: {metrics['teacher_forcing_ratio']:.2f}")
             if self.patience_counter >= self.config.patience:

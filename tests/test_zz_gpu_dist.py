@@ -54,3 +54,75 @@ def test_overlapped_bucketed_allreduce_is_the_same_step(tmp_path):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (nm, float((a - b).abs().max()), int((a != b).sum()), a.numel())
     finally:
         dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_train_the_same_model_as_one_process(request, tmp_path):
+    """The real Trainer(world_size=2) in two processes sharing the one card (gloo group; tests/conftest.py
+    started them at session start, tests/dist/two_rank_child.py): a gradient-penalty iteration and a plain
+    one with ragged lengths, per-rank noise and teacher forcing.  Both ranks must end with bit-identical
+    parameters, and these must equal a single process training the concatenated batch: the gradient average,
+    the global direction-loss denominator (RG.py:1095) and the shared teacher-forcing coins make the
+    data-parallel step the same function of the global batch."""
+    import numpy as np
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dist'))
+    import two_rank_common as C
+    import generative_mouse_trajectories_amd as gmt
+    from generative_mouse_trajectories_amd.trainer import dp_tf_coins
+    info = getattr(request.config, '_gmt_two_rank', None)
+    if info is None:
+        pytest.skip('the two-rank children are started at session start of a GPU run (tests/conftest.py)')
+    out = info['dir']
+    logs = ''
+    for r in range(2):
+        for nm in (f'trace{r}.log', f'stall{r}.log', f'out{r}.log'):
+            fp = os.path.join(out, nm)
+            if os.path.exists(fp):
+                logs += f'--- {nm}\n' + open(fp).read()[-3000:] + '\n'
+    assert info['status'] == 'ok', f"two-rank run {info['status']} after {info.get('seconds', 0):.0f}s\n{logs}"
+    r0, r1 = np.load(os.path.join(out, 'r0.npz')), np.load(os.path.join(out, 'r1.npz'))
+    for k in ('g', 'd', 'bufs', 'g_after', 'd_after', 'run_state'):
+        assert np.array_equal(r0[k], r1[k]), f'{k}: the two replicas differ'
+    # Trainer.train() on different shards: same learning rates / best loss / patience on both ranks (compared above),
+    # the plateau scheduler did act, and every checkpoint file exists once (rank 0 wrote it)
+    assert r0['run_state'][4] == 2 and (r0['run_state'][0] < 1e-4 or r0['run_state'][1] < 1e-4), r0['run_state']
+    assert sorted(f for f in os.listdir(os.path.join(out, 'ckpt')) if not f.endswith('_best.pt'))[0] == 'checkpoint_epoch_0.pt'
+    for it in range(C.ITERS):
+        assert np.array_equal(r0[f'd_grad{it}'], r1[f'd_grad{it}']) and np.array_equal(r0[f'g_grad{it}'], r1[f'g_grad{it}'])
+    # the same training in ONE process on the concatenated batch (rank 0's initial state: seed 100)
+    cfg = C.config(gmt)
+    torch.manual_seed(100)
+    G, D = gmt.Generator(cfg), gmt.Discriminator(cfg)
+    tr = gmt.Trainer(G, D, cfg, DEV, log_dir=str(tmp_path / 'ref'))
+    tr.epoch = C.EPOCH
+    G.train(); D.train()
+    batch = C.full_batch()
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    for it in range(C.ITERS):
+        nd, ng = C.global_noise(it)
+        m_d = tr.train_discriminator_step(batch, nd)
+        e = rel(r0[f'd_grad{it}'] / C.WORLD, tr.d_flat.grad.cpu().numpy())
+        assert e <= 2e-4, f'iteration {it}: averaged D gradient vs one process: {e:.2e}'
+        ng['tf_mask'] = dp_tf_coins(0, it, C.T, tr.get_teacher_forcing_ratio())
+        assert any(ng['tf_mask']) and not all(ng['tf_mask'])
+        m_g = tr.train_generator_step(batch, ng)
+        e = rel(r0[f'g_grad{it}'] / C.WORLD, tr.g_flat.grad.cpu().numpy())
+        assert e <= 2e-4, f'iteration {it}: averaged G gradient vs one process: {e:.2e}'
+        ref = [m_d[k] for k in sorted(m_d)] + [m_g[k] for k in sorted(m_g)]
+        names = sorted(m_d) + sorted(m_g)
+        both = 0.5 * (r0['metrics'][it] + r1['metrics'][it])
+        for nm, a, b, a0 in zip(names, both, ref, r0['metrics'][it]):
+            if nm == 'g_direction_loss':                  # global numerator / denominator: every rank reports the same
+                a = a0
+                assert r0['metrics'][it][names.index(nm)] == r1['metrics'][it][names.index(nm)]
+            if nm == 'd_gp' and it % 4 != 0:
+                assert a == 0 and b == 0
+                continue
+            assert abs(a - b) <= 2e-4 * max(abs(b), 1e-3), (it, nm, a, b)
+    # Adam moves a parameter by lr * m / (sqrt(v) + eps): where the gradient itself is at round-off level the
+    # direction of that step is not determined, so such entries are bounded by the step size (as in test_gpu_parity)
+    lr = cfg.learning_rate
+    for nm, a, b in (('G', r0['g'], tr.g_flat.flat.cpu().numpy()), ('D', r0['d'], tr.d_flat.flat.cpu().numpy())):
+        diff = np.abs(a - b)
+        assert diff.max() <= 2.0 * lr * C.ITERS, f'{nm} parameters: {diff.max():.2e}'
+        assert (diff > 0.02 * lr).mean() <= 0.02, f'{nm} parameters: {(diff > 0.02 * lr).mean():.3f} of the entries off'
