@@ -14,7 +14,9 @@ LIB = os.path.join(PKG, 'libgmt_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 # per-file extra flags: the f64 telemetry kernel must not fuse a*b+c (bit parity with MT.rs)
-EXTRA = {'telemetry.hip': ['-ffp-contract=off']}
+EXTRA = {'telemetry.hip': ['-ffp-contract=off'],
+         # the per-trajectory loss arithmetic follows the CPU reference operation by operation (no fused multiply-add)
+         'loss.hip': ['-ffp-contract=off']}
 
 
 def _deps_mtime() -> float:

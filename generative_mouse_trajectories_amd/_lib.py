@@ -10,7 +10,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libgmt_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 ERRORS = {-1: 'bad argument (null pointer / shape / alignment)', -2: 'unsupported configuration',
@@ -64,6 +64,13 @@ _SIGS = {
     'gmt_wgrad': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_ll, c_f, ctypes.c_uint, c_p],
     'gmt_wgrad_noalloc_init': [],
     'gmt_wgrad_noalloc': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_f, ctypes.c_uint, c_p],
+    'gmt_encoder_fwd': [c_p] * 9 + [c_i, c_i, c_i, c_f, c_f, c_p],
+    'gmt_dx_gemm': [c_p, c_p, c_p, c_p, c_f, c_ll, c_i, c_i, c_i, c_p],
+    'gmt_traj_from_seq': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    'gmt_traj_from_seq_bwd': [c_p, c_p, c_p, c_ll, c_ll, c_i, c_i, c_i, c_i, c_p],
+    'gmt_gen_loss_workspace_floats': [c_i, c_p],
+    'gmt_gen_loss_fwd': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
+    'gmt_gen_loss_bwd': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_ll, c_i, c_i, c_i, c_p],
     'gmt_spectral_norm_fwd': [c_p, c_i, c_f, c_i, c_p],
     'gmt_spectral_norm_bwd': [c_p, c_i, c_p],
     'gmt_gen_rollout_fwd': [c_p, c_p],

@@ -119,9 +119,16 @@ class Generator(nn.Module):
         angle = torch.atan2(diff[:, 1:2], diff[:, 0:1])
         return self.condition_encoder(torch.cat([start, end, distance, angle, z], dim=-1))
 
+    def prepack(self) -> None:
+        """Builds the cached fragment-major copies of the rollout's weights on the CURRENT stream (Trainer calls
+        this before it launches a rollout on a second stream, so that both streams find them complete)."""
+        lp = self.lstm
+        ops.gen_forward_packs(lp.weight_hh_l0, lp.weight_ih_l1, lp.weight_hh_l1, self.output_layer[0].weight)
+
     def _rollout(self, start, end, z, target_tm: Optional[torch.Tensor], tf_mask: Optional[torch.Tensor], T: int,
-                 dropout_seed: Optional[int] = None, stop_distance: float = 0.0):
-        """start/end (B,2), z (B,latent), target_tm (T,B,3) -> out (T,B,3); pads B to 32.
+                 dropout_seed: Optional[int] = None, stop_distance: float = 0.0, padded: bool = False):
+        """start/end (B,2), z (B,latent), target_tm (T,B,3) -> out (T,B,3); pads B to 32 (padded=True: returns
+        the padded (T,Bp,3) buffer itself, rows >= B are the rollout of zero inputs).
         stop_distance > 0 (sampling): also returns the per-row lengths the kernel found (int32 [B])."""
         L_.require_cuda(start, end, z)
         H = self.config.generator_hidden_dim
@@ -151,7 +158,17 @@ class Generator(nn.Module):
                                      torch.is_grad_enabled(), p_drop, dropout_seed, float(stop_distance), B, lens)
         if stop_distance > 0:
             return out[:, :B], lens[:B]
-        return out[:, :B]
+        return out if padded else out[:, :B]
+
+    def forward_tm(self, start, end, z, target_sequences: torch.Tensor, tf_mask: Sequence[bool],
+                   dropout_seed: Optional[int] = None) -> torch.Tensor:
+        """The training rollout in the kernels' own layout: out (T,Bp,3), time-major, batch padded to 32 rows -
+        what ops.traj_from_seq / ops.gen_aux_losses / Discriminator.forward_tm consume without a transpose."""
+        T = target_sequences.shape[1]
+        tm = None
+        if any(tf_mask):
+            tm = torch.tensor([1 if b else 0 for b in tf_mask], dtype=torch.uint8).to(start.device)
+        return self._rollout(start, end, z, target_sequences.transpose(0, 1), tm, T, dropout_seed, padded=True)
 
     def forward(self, start, end, z, target_sequences: Optional[torch.Tensor] = None,
                 target_lengths: Optional[torch.Tensor] = None, teacher_forcing_ratio: float = 0.0,
@@ -250,10 +267,19 @@ class Discriminator(nn.Module):
         The inter-layer dropout of nn.LSTM (RG.py:725) is a counter-based mask inside the kernels of the
         two layers it sits between (ops.LSTMLayerFn in_drop / out_drop; mask of layer l = seed + l,
         ops.dropout_keep_mask reproduces it) when the layer shapes allow, else F.dropout."""
-        feat = ops.kinematics_tm(pos_tm, dts_tm)
         sn_w = self.spectral_weights()
-        x = self.run_sequential(self.feature_encoder, feat, sn_w)
         H = self.config.discriminator_hidden_dim
+        # kinematic features + both encoder Linears + both LeakyReLUs: one launch (ops.EncoderFn); the LSTM layer
+        # that consumes x applies LeakyReLU'(x) to the gradient it returns (x_act_slope), the encoder's backward
+        # expects that
+        fe = self.feature_encoder
+        slope = float(fe[1].negative_slope)
+        fused_enc = self.fuse_input_gemm and fe[3].negative_slope == fe[1].negative_slope
+        if fused_enc:
+            w1, w2 = sn_w.pop(0), sn_w.pop(0)
+            x = ops.encoder(pos_tm, dts_tm, w1, fe[0].bias, w2, fe[2].bias, slope, 1e-8, True)
+        else:
+            x = self.run_sequential(self.feature_encoder, ops.kinematics_tm(pos_tm, dts_tm), sn_w)
         nl = self.config.discriminator_num_layers
         p = float(self.config.lstm_dropout) if self.training else 0.0
         fused = p > 0 and self.fuse_input_gemm and (2 * H) % 128 == 0
@@ -264,7 +290,8 @@ class Discriminator(nn.Module):
         for l in range(nl):
             h_all, h_final = ops.lstm_layer(x, lengths_i32, self.lstm.layer_weights(l), fuse_x=self.fuse_input_gemm,
                                             in_drop=(p, dropout_seed + l) if fused and l > 0 else none,
-                                            out_drop=(p, dropout_seed + l + 1) if fused and l + 1 < nl else none)
+                                            out_drop=(p, dropout_seed + l + 1) if fused and l + 1 < nl else none,
+                                            x_act_slope=slope if (fused_enc and l == 0) else -1.0)
             x = h_all
             if l + 1 < nl and p > 0 and not fused:
                 x = F.dropout(x, p, True)

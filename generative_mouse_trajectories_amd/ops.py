@@ -76,6 +76,44 @@ def kinematics_tm(pos: torch.Tensor, dts: torch.Tensor, eps: float = 1e-8) -> to
 
 
 # ----------------------------------------------------------------------------------------
+# derived-weight cache: packed / permuted / summed copies of the parameters are rebuilt once per
+# optimizer step, not once per call (include/gmt_hip.h: "Run once per optimizer step per weight")
+# ----------------------------------------------------------------------------------------
+_WEIGHTS_EPOCH = 0
+_DERIVED: dict = {}
+
+
+def weights_changed() -> None:
+    """Called by whoever writes parameters behind autograd's back (the fused Adam kernel, flat-buffer re-homing):
+    every cached derived weight is stale from here on."""
+    global _WEIGHTS_EPOCH
+    _WEIGHTS_EPOCH += 1
+    _DERIVED.clear()
+
+
+def derived(kind: str, tensors, build):
+    """build() -> derived tensor(s) of the PARAMETERS `tensors`, cached until those change.  An entry is valid only
+    for the very same tensor objects (weak references: a new tensor that happens to get a dead one's address or
+    id never matches), at the same autograd version (in-place torch updates bump it) and the same weights epoch
+    (the fused Adam kernel and the load paths, which write behind autograd's back, call weights_changed()).
+    Never pass temporaries (e.g. spectrally normalised weights, which are new tensors every call)."""
+    import weakref
+    key = (kind,) + tuple(id(t) for t in tensors)
+    hit = _DERIVED.get(key)
+    if hit is not None:
+        refs, versions, epoch, value = hit
+        if epoch == _WEIGHTS_EPOCH and all(r() is t for r, t in zip(refs, tensors)) \
+                and versions == tuple(t._version for t in tensors):
+            return value
+    if len(_DERIVED) > 512:                          # parameters updated by plain torch optimizers: bounded
+        _DERIVED.clear()
+    with torch.no_grad():
+        value = build()
+    _DERIVED[key] = (tuple(weakref.ref(t) for t in tensors), tuple(t._version for t in tensors), _WEIGHTS_EPOCH, value)
+    return value
+
+
+# ----------------------------------------------------------------------------------------
 # weight packing (fragment-major order of csrc/lstm_tile.h)
 # ----------------------------------------------------------------------------------------
 def pack_forward(ws: List[torch.Tensor], H: int, K: int, col0: int = 0, k_valid: Optional[int] = None) -> torch.Tensor:
@@ -137,88 +175,62 @@ def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False, x_drop: Tupl
 
 
 # ----------------------------------------------------------------------------------------
-# library GEMMs: which library, per shape
+# input-gradient contraction (csrc/dx_gemm.hip)
 # ----------------------------------------------------------------------------------------
-_BLAS_CHOICE: dict = {}
+def _dx_shape_ok(K: int, N: int) -> bool:
+    return N in (32, 64, 128, 256, 512) and K in (N, 2 * N, 4 * N) and K <= 1024 and not (N == 512 and K > 1024)
 
 
-def _time_mm(a, b, out, reps=3):
-    torch.mm(a, b, out=out)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        torch.mm(a, b, out=out)
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1)
+def pack_dx_weight(w_kn: torch.Tensor) -> torch.Tensor:
+    """w_kn [K, N] row-major = the B operand of dX = dA . W; fragment-major for gmt_dx_gemm."""
+    K, N = w_kn.shape
+    nw = min(4, N // 32)
+    ng = N // (32 * nw)
+    return _pack1(w_kn, K, K, 1 << 30, nw, ng, 32 * nw, N, 1)
 
 
-def mm_library(a: torch.Tensor, b: torch.Tensor):
-    """Which BLAS library torch should use for a @ b of this shape: rocBLAS and hipBLASLt each win some
-    of the tall-skinny fp32 shapes of this step (measured on MI355X, [528 384 x 512] x [512 x N]: N = 256
-    rocBLAS 121 vs 113 TFLOP/s, N = 128 hipBLASLt 114 vs 65).  Timed once per (M, N, K) and cached;
-    GMT_BLAS_AUTOTUNE=0 keeps torch's default."""
-    import os
-    key = (a.shape[0], b.shape[1], a.shape[1], a.device.index)
-    lib = _BLAS_CHOICE.get(key)
-    if lib is None:
-        lib = 'default'
-        if os.environ.get('GMT_BLAS_AUTOTUNE', '1') != '0' and a.shape[0] >= 65536:
-            cur = torch.backends.cuda.preferred_blas_library()
-            out = torch.empty(a.shape[0], b.shape[1], device=a.device, dtype=a.dtype)
-            best = None
-            for cand in ('cublaslt', 'cublas'):
-                try:
-                    torch.backends.cuda.preferred_blas_library(cand)
-                    ms = _time_mm(a, b, out)
-                except RuntimeError:
-                    continue
-                if best is None or ms < best[0]:
-                    best = (ms, cand)
-            torch.backends.cuda.preferred_blas_library(cur)
-            if best is not None:
-                lib = best[1]
-        _BLAS_CHOICE[key] = lib
-    return lib
+def dx_gemm(dA: torch.Tensor, w_pk: torch.Tensor, K: int, N: int, act: Optional[torch.Tensor] = None,
+            slope: float = 0.2) -> torch.Tensor:
+    """dA [nd, R, K] (or [R, K]) contiguous, w_pk [nd] packed by pack_dx_weight -> dX [R, N]
+    (times LeakyReLU'(act) when act [R, N] is given)."""
+    if dA.dim() == 2:
+        dA = dA.unsqueeze(0)
+    nd, R, _ = dA.shape
+    dX = torch.empty(R, N, device=dA.device, dtype=torch.float32)
+    L_.call('gmt_dx_gemm', L_.ptr(dA), L_.ptr(w_pk), L_.ptr(dX), L_.ptr(act), float(slope), R, K, N, nd, L_.stream(),
+            label=f'dx_gemm_K{K}_N{N}' + ('_act' if act is not None else ''))
+    return dX
 
 
-class _use_blas:
-    def __init__(self, lib):
-        self.lib = lib
-
-    def __enter__(self):
-        if self.lib != 'default':
-            self.prev = torch.backends.cuda.preferred_blas_library()
-            torch.backends.cuda.preferred_blas_library(self.lib)
-
-    def __exit__(self, *exc):
-        if self.lib != 'default':
-            torch.backends.cuda.preferred_blas_library(self.prev)
-
-
-def dx_from_da(da: torch.Tensor, w_ih: List[torch.Tensor], rows: int) -> torch.Tensor:
+def dx_from_da(da: torch.Tensor, w_ih: List[torch.Tensor], rows: int, act: Optional[torch.Tensor] = None,
+               slope: float = 0.2) -> torch.Tensor:
     """dx [rows, I] = sum over directions of da[d] [rows, 4H] @ W_ih[d] (4H axis in the buffers' unit-major
-    order): the one large library GEMM of a layer's backward."""
-    ws = [gate_perm(w.detach()) for w in w_ih]
-    a0 = da[0].view(rows, -1)
-    with _use_blas(mm_library(a0, ws[0])):
-        dx = torch.mm(a0, ws[0])
-        for d in range(1, len(ws)):
-            dx.addmm_(da[d].view(rows, -1), ws[d])
+    order), optionally times LeakyReLU'(act): one gmt_dx_gemm launch, both directions accumulated in registers.
+    Shapes outside the kernel's table (I not in {32 .. 512} or I not in {H, 2H, 4H}) use torch.mm."""
+    K, I = w_ih[0].shape
+    if _dx_shape_ok(K, I) and rows % TM == 0 and da.is_contiguous():
+        w_pk = derived('dx_pk', w_ih, lambda: torch.stack([pack_dx_weight(gate_perm(w.detach())) for w in w_ih]))
+        return dx_gemm(da.view(len(w_ih), rows, K), w_pk, K, I, act, slope)
+    ws = derived('dx_perm', w_ih, lambda: [gate_perm(w.detach()) for w in w_ih])
+    dx = torch.mm(da[0].view(rows, -1), ws[0])
+    for d in range(1, len(ws)):
+        dx.addmm_(da[d].view(rows, -1), ws[d])
+    if act is not None:
+        dx = dx * torch.where(act > 0, 1.0, slope)
     return dx
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b over the rows of x [..., I] (the per-timestep Linear layers of the feature
-    encoder, RG.py:713-718, applied to L*B rows).  Forward and dx are library GEMMs; the weight and
-    bias gradients - a [N x R] x [R x I] contraction with R ~ 5e5 - run on the split-K kernel."""
+    """y = x W^T + b over the rows of x [..., I]: the per-timestep Linear layers on the twice-differentiable
+    gradient-penalty path (composite.py; the ordinary critic call uses the fused encoder kernel).  Forward and
+    dx are torch ops (so that autograd can differentiate the backward once more); the weight and bias gradients
+    - a [N x R] x [R x I] contraction - run on the split-K kernel, and only when they are asked for."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
-        with _use_blas(mm_library(x.reshape(-1, x.shape[-1]), w.detach().t())):
-            return F.linear(x, w, b)
+        return F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
@@ -229,11 +241,11 @@ class LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         dx = None
         if ctx.needs_input_grad[0]:
-            with _use_blas(mm_library(dy2, w)):
-                dx = (dy2 @ w).view(x.shape)
+            dx = (dy2 @ w).view(x.shape)
         dW = db = None
-        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
-            dW, db = wgrad(dy2, x2, want_db=ctx.has_b)
+        # under create_graph=True (the penalty's inner autograd.grad) only dx is asked for: no wasted contraction
+        if not torch.is_grad_enabled() and (ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2])):
+            dW, db = wgrad(dy2.detach(), x2.detach(), want_db=ctx.has_b)
         return dx, dW, db
 
 
@@ -244,16 +256,27 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch
 # ----------------------------------------------------------------------------------------
 # packed bidirectional LSTM layer (RecurrentGAN.py:720-727, 764-778)
 # ----------------------------------------------------------------------------------------
+def lstm_bias(weights, nd: int) -> torch.Tensor:
+    """[nd, 4H] b_ih + b_hh per direction (cached per optimizer step)."""
+    bs = [weights[4 * d + k] for d in range(nd) for k in (2, 3)]
+    return derived('lstm_bias', bs, lambda: torch.stack([weights[4 * d + 2].detach() + weights[4 * d + 3].detach()
+                                                         for d in range(nd)]).contiguous())
+
+
 class LSTMLayerFn(torch.autograd.Function):
     """x [L,B,I] (B % 32 == 0), lengths int32 [B] -> (h_all [L,B,nd*H], h_final [B,nd*H]).
-    weights: per direction (w_ih [4H,I], w_hh [4H,H], b_ih [4H], b_hh [4H]).
+    weights: per direction (w_ih [4H,I], w_hh [4H,H], b_ih [4H], b_hh [4H]) - nn.Parameters (their packed forms
+    are cached per optimizer step).
     in_drop / out_drop = (p, seed): nn.LSTM's inter-layer dropout (RG.py:725) without a mask tensor.
     The layer with in_drop reads its input through the mask (forward and dW_ih) and returns dx
     w.r.t. the DROPPED input; the layer below it is given the same pair as out_drop and applies
-    the mask to that adjoint.  The two must be used together (models.Discriminator does)."""
+    the mask to that adjoint.  The two must be used together (models.Discriminator does).
+    x_act_slope >= 0: x is the output of a LeakyReLU with that slope (the feature encoder's, RG.py:717) and the
+    gradient returned for x is already multiplied by LeakyReLU'(x), i.e. it is the gradient of the
+    PRE-activation (the consumer, ops.EncoderFn, expects exactly that): one pass over [L*B, I] less."""
 
     @staticmethod
-    def forward(ctx, x, lengths, fuse_x, need_h_all, in_drop, out_drop, *weights):
+    def forward(ctx, x, lengths, fuse_x, need_h_all, in_drop, out_drop, x_act_slope, *weights):
         L_.require_cuda(x)
         nd = len(weights) // 4
         w_ih = [weights[4 * d] for d in range(nd)]
@@ -263,8 +286,8 @@ class LSTMLayerFn(torch.autograd.Function):
         assert B % TM == 0, 'pad the batch to a multiple of 32 rows'
         x = x.contiguous()
         dev = x.device
-        bias = torch.stack([weights[4 * d + 2].detach() + weights[4 * d + 3].detach() for d in range(nd)]).contiguous()
-        w_hh_pk = pack_forward(w_hh, H, H)
+        bias = lstm_bias(weights, nd)
+        w_hh_pk = derived('hh_pk', w_hh, lambda: pack_forward(w_hh, H, H))
         gates = torch.empty(nd, L, B, 4 * H, device=dev, dtype=torch.float32)
         c_all = torch.empty(nd, L, B, H, device=dev, dtype=torch.float32)
         h_all = torch.empty(L, B, nd * H, device=dev, dtype=torch.float32)
@@ -272,7 +295,7 @@ class LSTMLayerFn(torch.autograd.Function):
         if in_drop[0] > 0 and not (fuse_x and I % 128 == 0 and (L * B) % 16 == 0):
             raise L_.GmtError('fused input dropout needs the fused input contraction and I % 128 == 0')
         if fuse_x:
-            w_ih_pk = pack_forward(w_ih, H, I)
+            w_ih_pk = derived('ih_pk', w_ih, lambda: pack_forward(w_ih, H, I))
             L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(w_ih_pk), L_.ptr(w_hh_pk), L_.ptr(bias),
                     L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
                     L, B, I, H, nd, float(in_drop[0]), int(in_drop[1]), L_.stream(), label=f'lstm_fwd_fused_I{I // H}')
@@ -286,11 +309,17 @@ class LSTMLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x, lengths, gates, c_all, h_all, *weights)
         ctx.dims = (L, B, I, H, nd)
         ctx.drops = (in_drop, out_drop)
+        ctx.x_act_slope = x_act_slope
+        ctx.consumed = False
         ctx.set_materialize_grads(False)
         return h_all, h_final
 
     @staticmethod
     def backward(ctx, dh_all, dh_final):
+        if ctx.consumed:
+            raise L_.GmtError('this LSTM layer was already back-propagated: its saved gate buffer now holds '
+                              'd(pre-activation) (in-place backward); run the forward again instead of retain_graph')
+        ctx.consumed = True
         x, lengths, gates, c_all, h_all, *weights = ctx.saved_tensors
         L, B, I, H, nd = ctx.dims
         in_drop, out_drop = ctx.drops
@@ -300,7 +329,7 @@ class LSTMLayerFn(torch.autograd.Function):
             dh_all = dh_all.contiguous()
         if dh_final is not None:
             dh_final = dh_final.contiguous()
-        w_hh_pkT = pack_transposed(w_hh, H, 4 * H)
+        w_hh_pkT = derived('hh_pkT', w_hh, lambda: pack_transposed(w_hh, H, 4 * H))
         # `gates` is overwritten in place with d(pre-activation): the graph can be back-propagated once
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
                 L_.ptr(dh_all), L_.ptr(dh_final), None, None, None, None, None, L, B, H, nd,
@@ -310,18 +339,19 @@ class LSTMLayerFn(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = []
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = dx_from_da(da, w_ih, L * B).view(L, B, I)
-        need_w = any(ctx.needs_input_grad[6:])
+            act = x2 if ctx.x_act_slope >= 0 else None
+            dx = dx_from_da(da, w_ih, L * B, act, max(ctx.x_act_slope, 0.0)).view(L, B, I)
+        need_w = any(ctx.needs_input_grad[7:])
         if need_w:
             grads = _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd, in_drop)
         else:
             grads = [None] * (4 * nd)
-        return (dx, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, None, *grads)
 
 
 def lstm_layer(x, lengths_i32, weights, fuse_x: bool = True, need_h_all: bool = True,
-               in_drop: Tuple[float, int] = (0.0, 0), out_drop: Tuple[float, int] = (0.0, 0)):
-    return LSTMLayerFn.apply(x, lengths_i32, fuse_x, need_h_all, in_drop, out_drop, *weights)
+               in_drop: Tuple[float, int] = (0.0, 0), out_drop: Tuple[float, int] = (0.0, 0), x_act_slope: float = -1.0):
+    return LSTMLayerFn.apply(x, lengths_i32, fuse_x, need_h_all, in_drop, out_drop, x_act_slope, *weights)
 
 
 def _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd, x_drop=(0.0, 0)):
@@ -359,7 +389,7 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         da = torch.empty_like(gates)
         dct = torch.empty(nd, L, B, H, device=dev, dtype=torch.float32)
         dht = torch.empty(nd, L, B, H, device=dev, dtype=torch.float32)
-        w_hh_pkT = pack_transposed(w_hh, H, 4 * H)
+        w_hh_pkT = derived('hh_pkT', w_hh, lambda: pack_transposed(w_hh, H, 4 * H))
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
                 L_.ptr(dh_all), L_.ptr(dh_final), None, None, L_.ptr(da), L_.ptr(dct), L_.ptr(dht),
                 L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp')
@@ -380,8 +410,8 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         hhat_final = torch.empty(B, nd * H, device=dev, dtype=torch.float32)
         g_gates = torch.empty_like(gates)
         g_c = torch.empty_like(c_all)
-        w_ih_pk = pack_forward(w_ih, H, I)
-        w_hh_pk = pack_forward(w_hh, H, H)
+        w_ih_pk = derived('ih_pk', w_ih, lambda: pack_forward(w_ih, H, I))
+        w_hh_pk = derived('hh_pk', w_hh, lambda: pack_forward(w_hh, H, H))
         L_.call('gmt_lstm_layer_bwd2', L_.ptr(xhat), L_.ptr(w_ih_pk), L_.ptr(w_hh_pk), L_.ptr(lengths),
                 L_.ptr(gates), L_.ptr(c_all), L_.ptr(dct), L_.ptr(dht), L_.ptr(hhat_all), L_.ptr(hhat_final),
                 L_.ptr(g_gates), L_.ptr(g_c), L, B, I, H, nd, L_.stream(), label='lstm_bwd2')
@@ -414,13 +444,13 @@ class LSTMLayerGPFn(torch.autograd.Function):
         assert B % TM == 0
         x = x.contiguous()
         dev = x.device
-        bias = torch.stack([weights[4 * d + 2].detach() + weights[4 * d + 3].detach() for d in range(nd)]).contiguous()
+        bias = lstm_bias(weights, nd)
         gates = torch.empty(nd, L, B, 4 * H, device=dev, dtype=torch.float32)
         c_all = torch.empty(nd, L, B, H, device=dev, dtype=torch.float32)
         h_all = torch.empty(L, B, nd * H, device=dev, dtype=torch.float32)
         h_final = torch.empty(B, nd * H, device=dev, dtype=torch.float32)
-        w_ih_pk = pack_forward(w_ih, H, I)      # keep both alive until the launch is enqueued
-        w_hh_pk = pack_forward(w_hh, H, H)
+        w_ih_pk = derived('ih_pk', w_ih, lambda: pack_forward(w_ih, H, I))
+        w_hh_pk = derived('hh_pk', w_hh, lambda: pack_forward(w_hh, H, H))
         L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(w_ih_pk), L_.ptr(w_hh_pk),
                 L_.ptr(bias), L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
                 L, B, I, H, nd, 0.0, 0, L_.stream(), label=f'lstm_fwd_gp_I{I // H}')
@@ -444,7 +474,7 @@ class LSTMLayerGPFn(torch.autograd.Function):
         cont = lambda t: None if t is None else t.contiguous()
         dh_all, dh_final, dgates, dc = cont(dh_all), cont(dh_final), cont(dgates), cont(dc)
         da = torch.empty_like(gates)
-        w_hh_pkT = pack_transposed(w_hh, H, 4 * H)
+        w_hh_pkT = derived('hh_pkT', w_hh, lambda: pack_transposed(w_hh, H, 4 * H))
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
                 L_.ptr(dh_all), L_.ptr(dh_final), L_.ptr(dgates), L_.ptr(dc), L_.ptr(da), None, None,
                 L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp2')
@@ -453,6 +483,161 @@ class LSTMLayerGPFn(torch.autograd.Function):
             dx = dx_from_da(da, w_ih, L * B).view(L, B, I)
         grads = _lstm_weight_grads(da, x.view(L * B, I), h_all, w_hh, L, B, H, nd)
         return (dx, None, *grads)
+
+
+# ----------------------------------------------------------------------------------------
+# fused critic front end: kinematics + feature encoder (csrc/encoder.hip, RG.py:315-389, 712-717, 757-761)
+# ----------------------------------------------------------------------------------------
+class EncoderFn(torch.autograd.Function):
+    """pos [L,B,2], dts [L,B] (time-major, B % 32 == 0), the two (spectrally normalised) Linears ->
+    e [L,B,H] = lrelu(W2 lrelu(W1 feat(pos, dts) + b1) + b2) in ONE launch.
+    Backward: the incoming gradient is that of the second PRE-activation when grad_is_preact (the consuming LSTM
+    layer applied LeakyReLU'(e) in its dx kernel, ops.LSTMLayerFn x_act_slope); weight gradients on gmt_wgrad,
+    the Linear-2 input gradient with LeakyReLU'(h1) fused on gmt_dx_gemm, the 9-wide feature gradient by one
+    small library GEMM, kinematics backward on gmt_kinematics_bwd."""
+
+    @staticmethod
+    def forward(ctx, pos, dts, w1, b1, w2, b2, slope, eps, grad_is_preact):
+        L_.require_cuda(pos, dts, w1, w2)
+        pos, dts = pos.contiguous().float(), dts.contiguous().float()
+        L, B = dts.shape
+        H = w1.shape[0]
+        assert B % TM == 0 and w1.shape == (H, 9) and w2.shape == (H, H)
+        dev = pos.device
+        NW = H // 32
+        need_grad = any(ctx.needs_input_grad)
+        w1_pk = _pack1(w1, 16, 9, 1 << 30, NW, 1, 0, 1, 9)          # (normalised weights are new tensors every call)
+        w2_pk = _pack1(w2, H, H, 1 << 30, NW, 1, 0, 1, H)
+        e = torch.empty(L, B, H, device=dev, dtype=torch.float32)
+        feat = torch.empty(L, B, 9, device=dev, dtype=torch.float32) if need_grad else None
+        h1 = torch.empty(L, B, H, device=dev, dtype=torch.float32) if need_grad else None
+        L_.call('gmt_encoder_fwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(w1_pk), L_.ptr(b1.detach().contiguous()),
+                L_.ptr(w2_pk), L_.ptr(b2.detach().contiguous()), L_.ptr(feat), L_.ptr(h1), L_.ptr(e), L, B, H,
+                float(eps), float(slope), L_.stream(), label='encoder_fwd')
+        if need_grad:
+            ctx.save_for_backward(pos, dts, feat, h1, e, w1, w2)
+        ctx.cfg = (float(slope), float(eps), bool(grad_is_preact))
+        return e
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, dts, feat, h1, e, w1, w2 = ctx.saved_tensors
+        slope, eps, grad_is_preact = ctx.cfg
+        L, B = dts.shape
+        H = w1.shape[0]
+        R = L * B
+        g = g.contiguous().view(R, H)
+        if not grad_is_preact:
+            g = g * torch.where(e.view(R, H) > 0, 1.0, slope)
+        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need_w1 = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        need_w2 = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
+        h1v = h1.view(R, H)
+        d_w2 = d_b2 = d_w1 = d_b1 = gpos = gdts = None
+        if need_w2:
+            d_w2, d_b2 = wgrad(g, h1v, want_db=True)
+        if need_in or need_w1:
+            if _dx_shape_ok(H, H):
+                d_pre1 = dx_gemm(g, pack_dx_weight(w2.detach().contiguous()), H, H, h1v, slope)
+            else:
+                d_pre1 = (g @ w2.detach()) * torch.where(h1v > 0, 1.0, slope)
+            if need_w1:
+                d_w1, d_b1 = wgrad(d_pre1, feat.view(R, 9), want_db=True)
+            if need_in:
+                gfeat = torch.mm(d_pre1, w1.detach())                   # [R, 9]: 0.02 % of the step's FLOPs
+                gpos = torch.empty_like(pos)
+                gdts = torch.empty_like(dts)
+                L_.call('gmt_kinematics_bwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(gfeat), L_.ptr(gpos), L_.ptr(gdts),
+                        L, B, eps, L_.stream())
+        return gpos, gdts, d_w1, d_b1, d_w2, d_b2, None, None, None
+
+
+def encoder(pos, dts, w1, b1, w2, b2, slope: float = 0.2, eps: float = 1e-8, grad_is_preact: bool = False):
+    return EncoderFn.apply(pos, dts, w1, b1, w2, b2, slope, eps, grad_is_preact)
+
+
+# ----------------------------------------------------------------------------------------
+# trajectory bookkeeping and the generator's auxiliary losses (csrc/loss.hip)
+# ----------------------------------------------------------------------------------------
+class TrajFromSeqFn(torch.autograd.Function):
+    """(seq, starts) -> (pos_tm [T+1,Bp,2], dts_tm [T+1,Bp]): trajectory_to_absolute (RG.py:392-417) + the
+    F.pad(dt, (1, 0), 0.001) of RG.py:934 / 949 / 1061 + the move to the kernels' time-major, 32-row padded layout
+    in one launch.  seq is either batch-first [B,T,3] (a data batch) or time-major [T,Bp,3] (a rollout output)."""
+
+    @staticmethod
+    def forward(ctx, seq, starts, time_major, n_valid, Bp, first_dt):
+        L_.require_cuda(seq, starts)
+        seq = seq.contiguous()
+        starts = starts.contiguous().float()
+        if time_major:
+            T, bs, _ = seq.shape
+            assert bs == Bp
+            sb, st = 3, 3 * Bp
+        else:
+            bs, T, _ = seq.shape
+            assert bs == n_valid
+            sb, st = 3 * T, 3
+        pos = torch.empty(T + 1, Bp, 2, device=seq.device, dtype=torch.float32)
+        dts = torch.empty(T + 1, Bp, device=seq.device, dtype=torch.float32)
+        L_.call('gmt_traj_from_seq', L_.ptr(seq), sb, st, L_.ptr(starts), L_.ptr(pos), L_.ptr(dts), T, Bp, n_valid,
+                float(first_dt), L_.stream())
+        ctx.meta = (tuple(seq.shape), sb, st, T, Bp, n_valid, Bp if time_major else n_valid)
+        return pos, dts
+
+    @staticmethod
+    def backward(ctx, gpos, gdts):
+        shape, sb, st, T, Bp, n_valid, n_rows_out = ctx.meta
+        dev = (gpos if gpos is not None else gdts).device
+        gpos = torch.zeros(T + 1, Bp, 2, device=dev) if gpos is None else gpos.contiguous()
+        gdts = torch.zeros(T + 1, Bp, device=dev) if gdts is None else gdts.contiguous()
+        gseq = torch.empty(shape, device=dev, dtype=torch.float32)
+        L_.call('gmt_traj_from_seq_bwd', L_.ptr(gpos), L_.ptr(gdts), L_.ptr(gseq), sb, st, T, Bp, n_valid, n_rows_out,
+                L_.stream())
+        return gseq, None, None, None, None, None
+
+
+def traj_from_seq(seq, starts, time_major: bool, n_valid: int, Bp: int, first_dt: float = 0.001):
+    return TrajFromSeqFn.apply(seq, starts, time_major, n_valid, Bp, first_dt)
+
+
+class GenAuxLossFn(torch.autograd.Function):
+    """Every reduction of train_generator_step's auxiliary losses (RG.py:1072-1095) in one kernel:
+    seq_tm [T,Bp,3] (rollout output), starts / ends [B,2], lengths int32 [B] ->
+    scal [4] = (sum_b |final_b - end_b|^2, sum (1 - cos) mask, sum mask, 0)."""
+
+    @staticmethod
+    def forward(ctx, seq_tm, starts, ends, lengths):
+        L_.require_cuda(seq_tm, starts, ends, lengths)
+        import ctypes
+        seq_tm = seq_tm.contiguous()
+        T, Bp, _ = seq_tm.shape
+        B = starts.shape[0]
+        starts, ends = starts.contiguous().float(), ends.contiguous().float()
+        assert lengths.dtype == torch.int32 and lengths.numel() == B
+        need = ctypes.c_longlong(0)
+        L_.call('gmt_gen_loss_workspace_floats', B, ctypes.addressof(need), label='skip')
+        ws = torch.empty(need.value, device=seq_tm.device, dtype=torch.float32)
+        final = torch.empty(B, 2, device=seq_tm.device, dtype=torch.float32)
+        scal = torch.empty(4, device=seq_tm.device, dtype=torch.float32)
+        L_.call('gmt_gen_loss_fwd', L_.ptr(seq_tm), 3, 3 * Bp, L_.ptr(starts), L_.ptr(ends), L_.ptr(lengths), None,
+                L_.ptr(final), L_.ptr(scal), L_.ptr(ws), T, B, L_.stream())
+        ctx.save_for_backward(seq_tm, starts, ends, lengths, final)
+        return scal
+
+    @staticmethod
+    def backward(ctx, gscal):
+        seq_tm, starts, ends, lengths, final = ctx.saved_tensors
+        T, Bp, _ = seq_tm.shape
+        B = starts.shape[0]
+        gscal = gscal.contiguous().float()
+        gseq = torch.empty_like(seq_tm)
+        L_.call('gmt_gen_loss_bwd', L_.ptr(seq_tm), 3, 3 * Bp, L_.ptr(starts), L_.ptr(ends), L_.ptr(lengths), L_.ptr(final),
+                L_.ptr(gscal), L_.ptr(gseq), 3, 3 * Bp, T, Bp, B, L_.stream())
+        return gseq, None, None, None
+
+
+def gen_aux_losses(seq_tm, starts, ends, lengths_i32):
+    return GenAuxLossFn.apply(seq_tm, starts, ends, lengths_i32)
 
 
 # ----------------------------------------------------------------------------------------
@@ -539,6 +724,27 @@ def _pack1(w: torch.Tensor, K: int, k_valid: int, n_valid: int, n_waves: int, n_
     return out
 
 
+def gen_forward_packs(w_hh0, w_ih1, w_hh1, w1):
+    """Fragment-major copies of the generator's recurrent / head weights for gmt_gen_rollout_fwd (cached per
+    optimizer step; all four are nn.Parameters)."""
+    H = w_hh0.shape[1]
+    NW, HH = H // 32, H // 2
+    return derived('gen_fwd_pk', [w_hh0, w_ih1, w_hh1, w1], lambda: (
+        _pack1(w_hh0, H, H, 1 << 30, NW, 4, H, 1, H), _pack1(w_ih1, H, H, 1 << 30, NW, 4, H, 1, H),
+        _pack1(w_hh1, H, H, 1 << 30, NW, 4, H, 1, H), _pack1(w1, H, H, HH, max(1, H // 64), 1, 0, 1, H)))
+
+
+def gen_backward_packs(w_hh0, w_ih1, w_hh1, w1):
+    H = w_hh0.shape[1]
+    NW, HH = H // 32, H // 2
+
+    def build():
+        wl1 = torch.cat([w_hh1.detach(), w_ih1.detach()], dim=1).contiguous()        # [4H, 2H]
+        return (_pack1(w1, HH, HH, 1 << 30, NW, 1, 0, H, 1), _pack1(wl1, 4 * H, 4 * H, 1 << 30, NW, 2, H, 2 * H, 1),
+                _pack1(w_hh0, 4 * H, 4 * H, 1 << 30, NW, 1, 0, H, 1))
+    return derived('gen_bwd_pk', [w_hh0, w_ih1, w_hh1, w1], build)
+
+
 class GenRolloutFn(torch.autograd.Function):
     """Inputs (all fp32, cuda):
       g0 [B,4H] (unit-major columns 4*unit + gate), w_u [4H,7], w_hh0 [4H,H], w_ih1 [4H,H], w_hh1 [4H,H], bias1 [4H],
@@ -569,12 +775,13 @@ class GenRolloutFn(torch.autograd.Function):
             return t.data_ptr()
 
         a.g0 = P(g0)
-        a.w_u_pk = P(_pack1(w_u, 8, 7, 1 << 30, NW, 4, H, 1, 7))
-        a.w_hh0_pk = P(_pack1(w_hh0, H, H, 1 << 30, NW, 4, H, 1, H))
-        a.w_ih1_pk = P(_pack1(w_ih1, H, H, 1 << 30, NW, 4, H, 1, H))
-        a.w_hh1_pk = P(_pack1(w_hh1, H, H, 1 << 30, NW, 4, H, 1, H))
+        pk_hh0, pk_ih1, pk_hh1, pk_w1 = gen_forward_packs(w_hh0, w_ih1, w_hh1, w1)
+        a.w_u_pk = P(_pack1(w_u, 8, 7, 1 << 30, NW, 4, H, 1, 7))        # (w_u is assembled per call: not cached)
+        a.w_hh0_pk = P(pk_hh0)
+        a.w_ih1_pk = P(pk_ih1)
+        a.w_hh1_pk = P(pk_hh1)
         a.bias1 = P(bias1)
-        a.w1_pk = P(_pack1(w1, H, H, HH, max(1, H // 64), 1, 0, 1, H))
+        a.w1_pk = P(pk_w1)
         a.b1 = P(b1); a.w2 = P(w2); a.b2 = P(b2)
         a.starts = P(starts); a.ends = P(ends); a.init_in = P(init_in.reshape(3))
         a.target = P(target); a.tf_mask = P(tf_mask)
@@ -616,10 +823,7 @@ class GenRolloutFn(torch.autograd.Function):
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         d_out = d_out.contiguous()
         a = L_.GenBwdArgs()
-        w1T = _pack1(w1, HH, HH, 1 << 30, NW, 1, 0, H, 1)
-        wl1 = torch.cat([w_hh1.detach(), w_ih1.detach()], dim=1).contiguous()        # [4H, 2H]
-        wl1T = _pack1(wl1, 4 * H, 4 * H, 1 << 30, NW, 2, H, 2 * H, 1)
-        whh0T = _pack1(w_hh0, 4 * H, 4 * H, 1 << 30, NW, 1, 0, H, 1)
+        w1T, wl1T, whh0T = gen_backward_packs(w_hh0, w_ih1, w_hh1, w1)
         w_uP = torch.zeros(4 * H, 8, device=dev, dtype=torch.float32)
         w_uP[:, :7] = w_u.detach()
         w2c = w2.detach().contiguous()

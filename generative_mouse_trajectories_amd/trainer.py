@@ -55,6 +55,7 @@ class FlatParams:
             self.views_g.append(g)
         self.offsets = offs
         self.total = total
+        ops.weights_changed()
 
     def zero_grad(self):
         """Gradients start as None: autograd then hands each parameter its gradient tensor as is
@@ -104,6 +105,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count += 1
         ops.adam_step_(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'], g['eps'],
                        self.step_count, self.grad_scale)
+        ops.weights_changed()                # packed / permuted copies of the parameters are stale now
         for st in self.state.values():
             st['step'] = torch.tensor(float(self.step_count))
 
@@ -413,6 +415,7 @@ class Trainer:
         ts += [b for m in (self.generator, self.discriminator) for b in m.buffers()]
         for t_ in ts:
             broadcast_(t_, src, self.process_group)
+        ops.weights_changed()
         self.g_optimizer.step_count, self.d_optimizer.step_count, self.d_step, self._g_step = (int(v) for v in steps.tolist())
 
     def _tf_coins(self, T: int, tf_ratio: float) -> List[bool]:
@@ -452,6 +455,7 @@ class Trainer:
             # rollouts serialise (measured: +4 ms/step); priority streams come from a separate pool
             self._side = torch.cuda.Stream(device=self.device, priority=-1)
         main = torch.cuda.current_stream()
+        self.generator.prepack()             # the cached weight packs are built on the main stream, both streams read them
         self._side.wait_stream(main)
         T = sequences.shape[1]
         tf_ratio = self.get_teacher_forcing_ratio()
@@ -460,12 +464,16 @@ class Trainer:
         tf_mask = [bool(b) for b in tf_mask]
         with torch.cuda.stream(self._side):
             z = torch.randn(sequences.shape[0], self.config.latent_dim, device=self.device)
-            out = self.generator(starts, ends, z, target_sequences=sequences, target_lengths=lengths,
-                                 teacher_forcing_ratio=tf_ratio, tf_mask=tf_mask)
+            out = self.generator.forward_tm(starts, ends, z, sequences, tf_mask)
         for t_ in (starts, ends, sequences, lengths):
             t_.record_stream(self._side)
         self._spec = {'batch': real_batch, 'g_version': self._g_version, 'tf_ratio': tf_ratio, 'tf_mask': tf_mask, 'out': out,
                       'z': z}
+
+    def _critic_inputs(self, lengths: torch.Tensor, Bp: int) -> torch.Tensor:
+        """lengths + 1 (positions incl. the start point, RG.py:957 / 960 / 1064) as the kernels' int32 [Bp]
+        (clamped to >= 1 like RG.py:766; padding rows have length 1)."""
+        return _pad_batch((lengths + 1).to(dtype=torch.int32).clamp(min=1), Bp, 0, 1).contiguous()
 
     def train_discriminator_step(self, real_batch: Dict, noise: Optional[Dict] = None) -> Dict[str, float]:
         noise = noise or {}
@@ -473,21 +481,20 @@ class Trainer:
         self.d_optimizer.zero_grad()
         starts, ends, sequences, lengths = self._to_dev(real_batch)
         batch_size, T = sequences.shape[0], sequences.shape[1]
-        real_trajectories = trajectory_to_absolute(starts, sequences[:, :, :2])
-        real_dts_padded = F.pad(sequences[:, :, 2], (1, 0), value=0.001)
+        Bp = ops.pad_rows(batch_size)
+        G, D = self.generator, self.discriminator
+        # real_trajectories / real_dts_padded of RG.py:931-934, straight into the kernels' time-major padded layout
+        real_pos, real_dts = ops.traj_from_seq(sequences.float(), starts, False, batch_size, Bp)
         z = noise.get('z')
         z = torch.randn(batch_size, cfg.latent_dim, device=self.device) if z is None else z.to(self.device)
         if self.overlap_g_forward and self.device.type == 'cuda' and (self.d_step + 1) % max(1, cfg.n_critic) == 0:
             self._launch_speculative_g_forward(real_batch, starts, ends, sequences, lengths, noise.get('g_tf_mask'))
         with torch.no_grad():
-            fake_sequences, fake_lengths = self.generator(starts, ends, z, target_sequences=sequences,
-                                                          target_lengths=lengths, teacher_forcing_ratio=0.0,
-                                                          tf_mask=[False] * T)
-        fake_trajectories = trajectory_to_absolute(starts, fake_sequences[:, :, :2])
-        fake_dts_padded = F.pad(fake_sequences[:, :, 2], (1, 0), value=0.001)
-        lengths_plus_one = lengths + 1
-        real_score = self.discriminator(real_trajectories, real_dts_padded, lengths_plus_one)
-        fake_score = self.discriminator(fake_trajectories, fake_dts_padded, fake_lengths + 1)
+            fake_tm = G.forward_tm(starts, ends, z, sequences, [False] * T)              # (T,Bp,3), RG.py:938-944
+            fake_pos, fake_dts = ops.traj_from_seq(fake_tm, starts, True, batch_size, Bp)     # RG.py:946-949
+        lens_p1 = self._critic_inputs(lengths, Bp)
+        real_score = D.forward_tm(real_pos, real_dts, lens_p1)[:batch_size]
+        fake_score = D.forward_tm(fake_pos, fake_dts, lens_p1)[:batch_size]              # fake_lengths == lengths (RG.py:599-600)
         d_loss = fake_score.mean() - real_score.mean()
         gp = torch.zeros((), device=self.device)
         do_gp = (self.d_step % max(1, cfg.gp_every_n) == 0)
@@ -499,13 +506,14 @@ class Trainer:
                 idx = noise.get('gp_idx')
                 idx = torch.randperm(batch_size, device=self.device) if idx is None else idx.to(self.device)
                 idx = idx[:gp_bs]
-                sel = lambda t: t.index_select(0, idx)
             else:
-                sel = lambda t: t
+                idx = torch.arange(batch_size, device=self.device)
+            # the penalty's sub-batch, batch-first as compute_gradient_penalty takes it (RG.py:978-1003)
+            sel = lambda t_tm: t_tm.index_select(1, idx).transpose(0, 1)
             alpha = noise.get('alpha')
-            gp = compute_gradient_penalty(self.discriminator, sel(real_trajectories), sel(fake_trajectories),
-                                          sel(real_dts_padded), sel(fake_dts_padded), sel(lengths_plus_one),
-                                          self.device, None if alpha is None else alpha.to(self.device))
+            gp = compute_gradient_penalty(D, sel(real_pos), sel(fake_pos), sel(real_dts), sel(fake_dts),
+                                          (lengths + 1).index_select(0, idx), self.device,
+                                          None if alpha is None else alpha.to(self.device))
         total_loss = d_loss + cfg.gradient_penalty_weight * gp
         self._backward_and_sync(total_loss, self.d_flat, self._d_sync)
         self.d_optimizer.step()
@@ -519,6 +527,8 @@ class Trainer:
         self.g_optimizer.zero_grad()
         starts, ends, sequences, lengths = self._to_dev(real_batch)
         batch_size, T = sequences.shape[0], sequences.shape[1]
+        Bp = ops.pad_rows(batch_size)
+        G, D = self.generator, self.discriminator
         tf_ratio = self.get_teacher_forcing_ratio()
         tf_mask = noise.get('tf_mask')
         spec, self._spec = self._spec, None
@@ -527,40 +537,31 @@ class Trainer:
                 and (tf_mask is None or [bool(b) for b in tf_mask] == spec['tf_mask'])):
             # the rollout of this step was launched beside the D step's no-grad rollout (same G weights)
             torch.cuda.current_stream().wait_stream(self._side)
-            fake_sequences, fake_lengths = spec['out']
-            fake_sequences.record_stream(torch.cuda.current_stream())
+            fake_tm = spec['out']
+            fake_tm.record_stream(torch.cuda.current_stream())
         else:
             z = noise.get('z')
             z = torch.randn(batch_size, cfg.latent_dim, device=self.device) if z is None else z.to(self.device)
-            if tf_mask is None and self.world_size > 1:
+            if tf_mask is None:
                 tf_mask = self._tf_coins(T, tf_ratio)
-            fake_sequences, fake_lengths = self.generator(starts, ends, z, target_sequences=sequences,
-                                                          target_lengths=lengths, teacher_forcing_ratio=tf_ratio,
-                                                          tf_mask=tf_mask)
+            fake_tm = G.forward_tm(starts, ends, z, sequences, [bool(b) for b in tf_mask])     # RG.py:1051-1056
         self._g_step += 1
-        fake_deltas = fake_sequences[:, :, :2]
-        fake_trajectories = trajectory_to_absolute(starts, fake_deltas)
-        fake_dts_padded = F.pad(fake_sequences[:, :, 2], (1, 0), value=0.001)
+        fake_pos, fake_dts = ops.traj_from_seq(fake_tm, starts, True, batch_size, Bp)           # RG.py:1058-1061
         # the critic is a fixed function here: its weight gradients (which the reference computes
         # and discards at the next d_optimizer.zero_grad()) are skipped
         d_params = self.d_flat.params
         for p in d_params:
             p.requires_grad_(False)
         try:
-            fake_score = self.discriminator(fake_trajectories, fake_dts_padded, fake_lengths + 1)
+            fake_score = D.forward_tm(fake_pos, fake_dts, self._critic_inputs(lengths, Bp))[:batch_size]   # RG.py:1064
         finally:
             for p in d_params:
                 p.requires_grad_(True)
-        g_loss = -fake_score.mean()
-        final_pos = fake_trajectories[torch.arange(batch_size, device=self.device), fake_lengths]
-        endpoint_loss = F.mse_loss(final_pos, ends)
-        target_direction = ends - starts
-        target_direction = target_direction / (torch.sqrt((target_direction ** 2).sum(dim=-1, keepdim=True)) + 1e-8)
-        movement_norms = torch.sqrt((fake_deltas ** 2).sum(dim=-1, keepdim=True) + 1e-8)
-        movement_directions = fake_deltas / movement_norms
-        cosine_sim = (movement_directions * target_direction.unsqueeze(1)).sum(dim=-1)
-        mask = (torch.arange(T, device=self.device).unsqueeze(0) < fake_lengths.unsqueeze(1)).float()
-        dir_num, dir_den = ((1 - cosine_sim) * mask).sum(), mask.sum()
+        g_loss = -fake_score.mean()                                                              # RG.py:1069
+        # endpoint and direction losses (RG.py:1072-1095): every reduction in one kernel, gradient in one more
+        scal = ops.gen_aux_losses(fake_tm, starts, ends, lengths.to(torch.int32))
+        endpoint_loss = scal[0] / (2.0 * batch_size)                                             # F.mse_loss over (B, 2)
+        dir_num, dir_den = scal[1], scal[2]
         direction_loss = dir_num / dir_den
         dir_for_grad = direction_loss
         if self.world_size > 1:
@@ -568,7 +569,7 @@ class Trainer:
             # so numerator and denominator are summed over the ranks (one 2-element all-reduce) and the local term is
             # scaled so that the 1/world of the gradient average gives d(sum num / sum den) exactly
             import torch.distributed as dist
-            nd = torch.stack([dir_num.detach(), dir_den])
+            nd = torch.stack([dir_num.detach(), dir_den.detach()])
             all_reduce_sum(nd, self.process_group)
             direction_loss = nd[0] / nd[1]
             dir_for_grad = dir_num * (float(dist.get_world_size(self.process_group)) / nd[1])
@@ -651,6 +652,7 @@ class Trainer:
         self.g_optimizer.load_state_dict(checkpoint['g_optimizer_state_dict'])
         self.d_optimizer.load_state_dict(checkpoint['d_optimizer_state_dict'])
         self.best_loss = checkpoint.get('best_loss', float('inf'))
+        ops.weights_changed()
         self.sync_replicas()
         print(f'Loaded checkpoint from epoch {self.epoch}')
 

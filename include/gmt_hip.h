@@ -39,7 +39,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define GMT_ERR_WORKSPACE (-4)    /* caller's workspace is too small                     */
 
 /* ABI version of this header; gmt_version() of the loaded library must match. */
-#define GMT_ABI_VERSION 4
+#define GMT_ABI_VERSION 5
 int gmt_version(void);
 
 /* ---- kinematic features, "mode A" ---------------------------------------------------
@@ -52,6 +52,51 @@ int gmt_kinematics_fwd(const float* pos, const float* dts, float* feat,
  * gpos [L][B][2], gdts [L][B]. */
 int gmt_kinematics_bwd(const float* pos, const float* dts, const float* gfeat,
                        float* gpos, float* gdts, int L, int B, float eps, hipStream_t stream);
+
+/* ---- fused critic front end ----------------------------------------------------------------
+ * Replaces compute_kinematics (RG.py:315-389, called at RG.py:757) + Discriminator.feature_encoder
+ * (RG.py:712-717, applied at RG.py:761) in one launch: pos [L][B][2], dts [L][B] ->
+ * e [L][B][H] = lrelu(W2 lrelu(W1 feat + b1) + b2), slope 0.2 in the reference.  w1_pk / w2_pk: the
+ * (spectrally normalised) weights [H][9] / [H][H] packed by gmt_pack_weight (K 16 with k_valid 9 / K H;
+ * n_waves H/32, 1 gate, stride_k 1, stride_n 9 / H).  feat [L][B][9] and h1 [L][B][H] (first activation)
+ * are optional outputs for the backward pass.  B % 32 == 0, H in {32, 64, 128, 256}. */
+int gmt_encoder_fwd(const float* pos, const float* dts, const float* w1_pk, const float* b1,
+                    const float* w2_pk, const float* b2, float* feat, float* h1, float* e,
+                    int L, int B, int H, float eps, float slope, hipStream_t stream);
+
+/* ---- input-gradient contraction -----------------------------------------------------------------
+ * dX[r][n] = (sum_d sum_k dA[d][r][k] * W_d[k][n]) * (act ? (act[r][n] > 0 ? 1 : slope) : 1): the dx GEMMs autograd
+ * runs for RG.py:1021 / 1109 - the input gradient of an LSTM layer (dA = d(pre-activation) of both directions,
+ * K = 4H, W = W_ih with its 4H axis in the buffers' unit-major order) and of the encoder's Linears with their
+ * LeakyReLU backward fused (act = the layer's activated output).  dA [ndir][R][K], dX [R][N] contiguous;
+ * w_pk [ndir] packed by gmt_pack_weight (K, n_waves min(4, N/32), n_gates N / (32 n_waves), gate_stride
+ * 32 n_waves, stride_k N, stride_n 1).  N in {32, 64, 128, 256, 512}, K in {N, 2N, 4N} (<= 1024), R % 32 == 0. */
+int gmt_dx_gemm(const float* dA, const float* w_pk, float* dX, const float* act, float slope,
+                long long R, int K, int N, int ndir, hipStream_t stream);
+
+/* ---- trajectory bookkeeping and generator losses ----------------------------------------------------
+ * gmt_traj_from_seq: trajectory_to_absolute (RG.py:392-417) + F.pad(dt, (1, 0), first_dt) (RG.py:934, 949, 1061)
+ * + the transposition to time-major: seq element (b, t, c) at seq[b*stride_b + t*stride_t + c], c = dx, dy, dt;
+ * starts [B][2] -> pos [T+1][B][2], dts [T+1][B].  Rows >= n_valid (batch padding) are zero.  _bwd: the reverse
+ * cumulative sum, (gpos, gdts) -> gseq in the given strides; gseq has n_rows_out rows (n_valid <= n_rows_out <= B),
+ * those >= n_valid are zero. */
+int gmt_traj_from_seq(const float* seq, long long stride_b, long long stride_t, const float* starts,
+                      float* pos, float* dts, int T, int B, int n_valid, float first_dt, hipStream_t stream);
+int gmt_traj_from_seq_bwd(const float* gpos, const float* gdts, float* gseq, long long stride_b,
+                          long long stride_t, int T, int B, int n_valid, int n_rows_out, hipStream_t stream);
+/* gmt_gen_loss_fwd: every reduction of train_generator_step (RG.py:1069-1095) in one pass:
+ * scal[0] = sum_b |final_b - end_b|^2 (final_b = fake_traj[b, len_b], RG.py:1072), scal[1] = sum (1 - cos) mask,
+ * scal[2] = sum mask (RG.py:1077-1095), scal[3] = sum_b score_b (score may be NULL).  final_pos [n_valid][2] is
+ * saved for the backward; workspace: gmt_gen_loss_workspace_floats.  _bwd: gseq = gscal[0] d(scal[0]) +
+ * gscal[1] d(scal[1]) w.r.t. the sequence (gscal: 2 device floats), rows >= n_valid zero. */
+int gmt_gen_loss_workspace_floats(int n_valid, long long* floats_out);
+int gmt_gen_loss_fwd(const float* seq, long long stride_b, long long stride_t, const float* starts,
+                     const float* ends, const int* lengths, const float* score, float* final_pos,
+                     float* scal, float* workspace, int T, int n_valid, hipStream_t stream);
+int gmt_gen_loss_bwd(const float* seq, long long stride_b, long long stride_t, const float* starts,
+                     const float* ends, const int* lengths, const float* final_pos, const float* gscal,
+                     float* gseq, long long gstride_b, long long gstride_t, int T, int B, int n_valid,
+                     hipStream_t stream);
 
 /* ---- telemetry kinematics, "mode B", f64 ----------------------------------------------
  * Replaces MouseCollector::calculate_collection_attributes, MT.rs:550-654

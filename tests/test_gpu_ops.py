@@ -197,3 +197,97 @@ def test_linear_fn_matches_autograd(ops):
     gx64, = torch.autograd.grad(torch.nn.functional.linear(x64, w64, b.double()), x64, g.double(), create_graph=True)
     (gx64 ** 2).sum().backward()
     H.assert_close(w.grad, w64.grad, 1e-5, 'd2w')
+
+
+# ---- round 2: fused critic front end, dx contraction, trajectory bookkeeping, generator losses -----------------
+@pytest.mark.parametrize('Hd,B,L', [(128, 96, 37), (32, 32, 9), (64, 64, 5), (256, 32, 12)])
+def test_fused_encoder_vs_oracle(ops, Hd, B, L):
+    """gmt_encoder_fwd (kinematics + Linear 9->H + LeakyReLU + Linear H->H + LeakyReLU, RG.py:315-389, 712-717)
+    and its backward (gmt_dx_gemm with the fused LeakyReLU', gmt_wgrad, gmt_kinematics_bwd) against the same
+    composition in fp64 torch ops."""
+    g = torch.Generator().manual_seed(Hd + L)
+    pos = torch.rand(B, 1, 2, generator=g) + torch.cumsum(torch.randn(B, L, 2, generator=g) * 0.01, 1)
+    dts = torch.rand(B, L, generator=g) * 0.02 + 0.004
+    w1 = torch.randn(Hd, 9, generator=g) * 0.05; b1 = torch.randn(Hd, generator=g) * 0.1
+    w2 = torch.randn(Hd, Hd, generator=g) / math.sqrt(Hd); b2 = torch.randn(Hd, generator=g) * 0.1
+    w = torch.randn(B, L, Hd, generator=g)
+    leaves = [t.double().requires_grad_(True) for t in (pos, dts, w1, b1, w2, b2)]
+    f = O.kinematics(leaves[0], leaves[1])
+    h1 = torch.nn.functional.leaky_relu(torch.nn.functional.linear(f, leaves[2], leaves[3]), 0.2)
+    e64 = torch.nn.functional.leaky_relu(torch.nn.functional.linear(h1, leaves[4], leaves[5]), 0.2)
+    (e64 * w.double()).sum().backward()
+    dl = [pos.transpose(0, 1).contiguous(), dts.t().contiguous(), w1, b1, w2, b2]
+    dl = [t.to(DEV).requires_grad_(True) for t in dl]
+    for pre in (False, True):
+        for t in dl:
+            t.grad = None
+        e = ops.encoder(*dl, 0.2, 1e-8, pre)
+        H.assert_close(e.transpose(0, 1), e64.detach(), 2e-5, f'encoder output H={Hd}')
+        gin = w.to(DEV).transpose(0, 1)
+        if pre:                                   # the consumer hands over d(pre-activation): apply LeakyReLU' here
+            gin = gin * torch.where(e.detach() > 0, 1.0, 0.2)
+        e.backward(gin.contiguous())
+        H.assert_close(dl[0].grad.transpose(0, 1), leaves[0].grad, 1e-4, 'encoder gpos')
+        H.assert_close(dl[1].grad.t(), leaves[1].grad, 1e-4, 'encoder gdts')
+        for k in range(2, 6):
+            H.assert_close(dl[k].grad, leaves[k].grad, 1e-4, f'encoder weight grad {k}')
+
+
+@pytest.mark.parametrize('K,N,nd,R', [(512, 256, 2, 32 * 700), (512, 128, 2, 32 * 513), (128, 128, 1, 32 * 40),
+                                       (128, 32, 2, 64), (256, 64, 1, 32 * 33), (1024, 256, 2, 32 * 20), (512, 512, 1, 32 * 9)])
+def test_dx_gemm_vs_fp64(ops, K, N, nd, R):
+    """gmt_dx_gemm: dX = sum_d dA_d W_d, optionally times LeakyReLU'(act) - more tiles than workgroups, both
+    tile-walk parities, one and two directions."""
+    g = torch.Generator().manual_seed(K + N + R)
+    dA = torch.randn(nd, R, K, generator=g)
+    W = torch.randn(nd, K, N, generator=g) / math.sqrt(K)
+    act = torch.randn(R, N, generator=g)
+    ref = sum(dA[d].double() @ W[d].double() for d in range(nd))
+    w_pk = torch.stack([ops.pack_dx_weight(W[d].to(DEV).contiguous()) for d in range(nd)])
+    out = ops.dx_gemm(dA.to(DEV), w_pk, K, N)
+    H.assert_close(out, ref, 2e-6, 'dx_gemm')
+    out = ops.dx_gemm(dA.to(DEV), w_pk, K, N, act.to(DEV), 0.2)
+    H.assert_close(out, ref * torch.where(act > 0, 1.0, 0.2).double(), 2e-6, 'dx_gemm with LeakyReLU\'')
+
+
+def test_traj_from_seq_and_generator_losses_vs_oracle(ops):
+    """gmt_traj_from_seq (RG.py:392-417 + the dt padding) and gmt_gen_loss_fwd / _bwd (RG.py:1072-1095) against the
+    oracle's generator_losses and autograd, ragged lengths, batch padding rows, both sequence layouts."""
+    B, T = 70, 19
+    Bp = ops.pad_rows(B)
+    g = torch.Generator().manual_seed(5)
+    lengths = torch.randint(1, T + 1, (B,), generator=g)
+    lengths[0] = T
+    starts = torch.rand(B, 2, generator=g)
+    ends = starts + 0.2 * torch.randn(B, 2, generator=g)
+    seq = torch.cat([torch.randn(B, T, 2, generator=g) * 0.01, torch.rand(B, T, 1, generator=g) * 0.02 + 0.004], -1)
+    seq[3, 2, :2] = 0.0                                   # a zero step: the eps inside the square root matters
+    # batch-first data layout
+    pos, dts = ops.traj_from_seq(seq.to(DEV), starts.to(DEV), False, B, Bp)
+    ref_pos = O.to_absolute(starts, seq[:, :, :2])
+    assert torch.equal(pos[:, :B].transpose(0, 1).cpu(), ref_pos)             # the CPU reference's association, bit for bit
+    assert torch.equal(dts[:, :B].t().cpu(), torch.nn.functional.pad(seq[:, :, 2], (1, 0), value=0.001))
+    assert float(pos[:, B:].abs().max()) == 0 and float(dts[:, B:].abs().max()) == 0
+    # time-major rollout layout, with gradients
+    seq_tm = torch.zeros(T, Bp, 3)
+    seq_tm[:, :B] = seq.transpose(0, 1)
+    seq_tm[:, B:] = 7.0                                   # garbage in the padding rows must not leak
+    sg = seq_tm.to(DEV).requires_grad_(True)
+    pos2, dts2 = ops.traj_from_seq(sg, starts.to(DEV), True, B, Bp)
+    assert torch.equal(pos2[:, :B].cpu(), pos[:, :B].cpu()) and torch.equal(dts2[:, :B].cpu(), dts[:, :B].cpu())
+    wp, wd = torch.randn(T + 1, Bp, 2, generator=g), torch.randn(T + 1, Bp, generator=g)
+    scal = ops.gen_aux_losses(sg, starts.to(DEV), ends.to(DEV), lengths.to(torch.int32).to(DEV))
+    cw = torch.tensor([0.7, -1.3, 0.0, 0.0])
+    ((pos2 * wp.to(DEV)).sum() + (dts2 * wd.to(DEV)).sum() + (scal * cw.to(DEV)).sum()).backward()
+    s64 = seq.double().requires_grad_(True)
+    p64 = O.to_absolute(starts.double(), s64[:, :, :2])
+    d64 = torch.nn.functional.pad(s64[:, :, 2], (1, 0), value=0.001)
+    _, endpoint, direction = O.generator_losses(s64, torch.zeros(B, 1, dtype=torch.float64), starts.double(), ends.double(), lengths)
+    mask_sum = float(lengths.sum())
+    H.assert_close(scal[:3].cpu(), torch.stack([endpoint * 2 * B, direction * mask_sum, torch.tensor(mask_sum, dtype=torch.float64)]).detach(),
+                   2e-6, 'loss sums')
+    tot = (p64 * wp[:, :B].transpose(0, 1).double()).sum() + (d64 * wd[:, :B].t().double()).sum() \
+        + 0.7 * endpoint * 2 * B - 1.3 * direction * mask_sum
+    tot.backward()
+    H.assert_close(sg.grad[:, :B].transpose(0, 1), s64.grad, 2e-5, 'd(sequence)')
+    assert float(sg.grad[:, B:].abs().max()) == 0

@@ -89,10 +89,21 @@ def _replay(tag, cfg_over, B, T, lengths, full, gtol):
     tr = gmt.Trainer(G, D, cfg, torch.device(DEV), '/tmp/runs_gpu')
     batch = H.batch_t(B, T, 23, lengths)
     plan = [s.split(':') for s in g[f'{tag}_plan']]
+    # the same steps on the fp64 oracle: where a golden (fp32 reference) gradient is itself further than the
+    # tolerance from the exact one - the critic's gradient without the penalty term is a small difference of two
+    # large sums - the HIP result must be no further from the exact gradient than the reference is
+    oc64, Pg64, Pd64, Bd64 = H.oracle_models(cfg_over, 21, 22, torch.float64)
+    og64, od64 = {}, {}
+    b64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in batch.items()}
+    exact = {}
 
     def check(name, val, rtol):
         ref = g[name]
         val = val.detach().cpu().numpy()
+        if full and name in exact and H.relerr(val, ref) > rtol:
+            e_ref, e_hip = H.relerr(ref, exact[name]), H.relerr(val, exact[name])
+            assert e_hip <= 1.25 * e_ref + 1e-5, f'{name}: {e_hip:.2e} from the fp64 oracle, the reference itself {e_ref:.2e}'
+            return
         if not full:
             val = PG.digest(val)
             e = np.abs(val - ref)
@@ -111,11 +122,20 @@ def _replay(tag, cfg_over, B, T, lengths, full, gtol):
                 noise['alpha'] = H.t(g[f'{tag}_s{i}_alpha'])
                 if f'{tag}_s{i}_gp_idx' in g:
                     noise['gp_idx'] = H.t(g[f'{tag}_s{i}_gp_idx'])
+            d_step = tr.d_step
             m = tr.train_discriminator_step(batch, noise)
             model, opt = D, tr.d_optimizer
+            if full:
+                n64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in noise.items()}
+                _, g64, _ = O.discriminator_step(Pg64, Pd64, Bd64, od64, b64, n64, oc64, d_step)
         else:
-            m = tr.train_generator_step(batch, {'z': z, 'tf_mask': list(g[f'{tag}_s{i}_tf_mask'])})
+            mask = list(g[f'{tag}_s{i}_tf_mask'])
+            m = tr.train_generator_step(batch, {'z': z, 'tf_mask': mask})
             model, opt = G, tr.g_optimizer
+            if full:
+                _, g64, _ = O.generator_step(Pg64, Pd64, Bd64, og64, b64, {'z': z.double()}, oc64, mask, 0.0)
+        if full:
+            exact = {f'{tag}_s{i}_grad/{k}': v.detach().numpy() for k, v in g64.items() if v is not None}
         for k, v in ref_m.items():
             assert abs(m[k] - v) <= TOL * max(abs(v), 1e-3), f'step {i} metric {k}: {m[k]} vs {v}'
         for k, p in model.named_parameters():
