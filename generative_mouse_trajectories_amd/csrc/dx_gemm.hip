@@ -91,6 +91,141 @@ void dx_gemm_kernel(const float* __restrict__ dA, const float* __restrict__ w_pk
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The hot shapes (N a multiple of 128, K <= 512: the H = 128 layers and the encoder) keep their weight block
+// RESIDENT: a workgroup owns one 128-column block of one direction's W at a time - 4 waves x 32 columns x K rows =
+// K/2 VGPRs a lane, loaded once per pass - and walks its tiles with nothing but dA flowing: global -> registers
+// (one float4 ahead of each group of MFMAs) -> LDS (transposed, double-buffered, written between the MFMAs of the
+// previous tile) -> MFMA A operand.  No weight traffic and no vmcnt stall inside a tile.  Directions are PASSES of
+// the same workgroup over the same tiles: pass d > 0 starts its accumulators from the partial dX the workgroup
+// itself stored in pass d - 1 (prefetched a tile ahead), so there is still one launch and no cross-workgroup
+// dependency.  One wave per SIMD (the weights fill the register file), like lstm_bwd_kernel.
+template <int K, int N>
+__global__ __launch_bounds__(256, 1)
+void dx_gemm_res_kernel(const float* __restrict__ dA, const float* __restrict__ w_pk, float* __restrict__ dX,
+                        const float* __restrict__ act, float slope, long long R, int ndir, long long n_tiles)
+{
+    constexpr int NT = 256, KS = K / 2, KQ = K / 4;
+    constexpr int XS = (GMT_TM * KQ) / NT;              // float4 of dA per thread and tile (K = 512: 16)
+    constexpr int NGRP = KS / 8;                        // MFMA groups per tile (gmt_mma_resident, one-gate form)
+    constexpr int HALF = NGRP / 2;
+    static_assert(XS <= HALF, "one staged float4 per group");
+    constexpr int n_nb = N / 128;
+    extern __shared__ float smem[];                     // [2][K][LDA]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lo = lane & 31;
+    const int nb = blockIdx.x % n_nb;
+    const long long worker = blockIdx.x / n_nb, workers = gridDim.x / n_nb;
+    if (worker >= n_tiles) return;
+    const long long last_tile = worker + ((n_tiles - 1 - worker) / workers) * workers;   // this worker's final tile
+    // addressing: one uniform base per tile (scalar registers) + ONE per-lane offset per buffer, laundered at each use
+    // so that `offset + constant` is recomputed instead of being kept in a register per constant
+    const unsigned c_off = (unsigned)(4 * hi * N + nb * 128 + wave * 32 + lo);           // within a tile of dX / act
+    const unsigned s_off = (unsigned)((4 * (tid % KQ)) * GMT_LDA + tid / KQ);            // within an LDS buffer
+    static_assert(NT % KQ == 0 || KQ % NT == 0, "staging map");
+
+    float4 xs[XS];
+    float cin[16], actv[16];
+    for (int d = 0; d < ndir; ++d) {
+        float wr[1][KS];
+        gmt_load_resident<1, KS>(wr, reinterpret_cast<const float4*>(w_pk) + ((size_t)d * (N / 32) + nb * 4 + wave) * (K / 8) * 64, lane);
+        const float* Ad = dA + (size_t)d * R * K;
+        const bool first = (d == 0), final = (d == ndir - 1);
+        auto a_load1 = [&](long long tile, int j) {
+            const float4* src = reinterpret_cast<const float4*>(Ad + (size_t)tile * GMT_TM * K) + j * NT;   // uniform
+            xs[j] = src[tid];
+        };
+        auto a_store1 = [&](float* buf, int j) {
+            // item tid + j NT: row (tid + j NT) / KQ, float4 column (tid + j NT) % KQ
+            float* p = buf + gmt_opaque_u(s_off) + (NT >= KQ ? j * (NT / KQ) : (4 * ((j * NT) % KQ)) * GMT_LDA + (j * NT) / KQ);
+            p[0] = xs[j].x; p[GMT_LDA] = xs[j].y; p[2 * GMT_LDA] = xs[j].z; p[3 * GMT_LDA] = xs[j].w;
+        };
+        // prologue: tile 0 -> LDS[0], tile 1 -> registers, partial sums of tile 0
+        long long tile = worker;
+#pragma unroll
+        for (int j = 0; j < XS; ++j) a_load1(tile, j);
+#pragma unroll
+        for (int j = 0; j < XS; ++j) a_store1(smem, j);
+        {
+            const long long t1 = tile + workers <= last_tile ? tile + workers : last_tile;
+#pragma unroll
+            for (int j = 0; j < XS; ++j) a_load1(t1, j);
+        }
+        {
+            const float* cb = dX + (size_t)tile * GMT_TM * N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cin[r] = first ? 0.f : cb[c_off + ((r & 3) + 8 * (r >> 2)) * N];
+        }
+        __syncthreads();
+        int cur = 0;
+        for (; tile <= last_tile; tile += workers) {
+            const long long t1 = tile + workers <= last_tile ? tile + workers : last_tile;
+            const long long t2 = t1 + workers <= last_tile ? t1 + workers : last_tile;
+            float* a_cur = smem + (size_t)cur * K * GMT_LDA;
+            float* a_nxt = smem + (size_t)(cur ^ 1) * K * GMT_LDA;
+            f32x16 acc[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = cin[r];
+            float* c0 = dX + (size_t)tile * GMT_TM * N;                // uniform bases
+            const float* c1 = dX + (size_t)t1 * GMT_TM * N;
+            const float* ab = act ? act + (size_t)tile * GMT_TM * N : dX;
+            gmt_mma_resident<1, KS>(acc, a_cur, wr, lane, nullptr, [&](int grp) {
+                // first half of the groups: tile t1 (in registers since the previous trip) -> the other LDS buffer,
+                // and this tile's activation values; second half: tile t2 -> registers, tile t1's partial sums
+                if (grp < HALF) {
+#pragma unroll
+                    for (int j = 0; j < XS; ++j)
+                        if ((j * HALF) / XS == grp) a_store1(a_nxt, j);
+                    if (final && act) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if ((r * HALF) / 16 == grp) actv[r] = ab[gmt_opaque_u(c_off) + ((r & 3) + 8 * (r >> 2)) * N];
+                    }
+                } else {
+                    const int g2 = grp - HALF;
+#pragma unroll
+                    for (int j = 0; j < XS; ++j)
+                        if ((j * HALF) / XS == g2) a_load1(t2, j);
+                    if (!first) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if ((r * HALF) / 16 == g2) cin[r] = c1[gmt_opaque_u(c_off) + ((r & 3) + 8 * (r >> 2)) * N];
+                    }
+                }
+            });
+            {
+                float* cw = c0 + gmt_opaque_u(c_off);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[0][r];
+                    if (final && act) v *= (actv[r] > 0.f) ? 1.f : slope;
+                    cw[((r & 3) + 8 * (r >> 2)) * N] = v;
+                }
+            }
+            __syncthreads();                            // every wave is done reading a_cur and writing a_nxt
+            cur ^= 1;
+        }
+    }
+}
+
+template <int K, int N>
+int launch_dx_res(const float* dA, const float* w_pk, float* dX, const float* act, float slope, long long R,
+                  int ndir, hipStream_t stream)
+{
+    const size_t lds = (size_t)2 * K * GMT_LDA * sizeof(float);
+    auto k = dx_gemm_res_kernel<K, N>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return GMT_ERR_HIP;
+    const long long n_tiles = R / GMT_TM;
+    constexpr int n_nb = N / 128;
+    long long workers = 256 / n_nb;
+    if (workers > n_tiles) workers = n_tiles;
+    hipLaunchKernelGGL(k, dim3((unsigned)(workers * n_nb)), dim3(256), lds, stream, dA, w_pk, dX, act, slope, R, ndir, n_tiles);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
 template <int NWD, int NG, int K>
 int launch_dx(const float* dA, const float* w_pk, float* dX, const float* act, float slope, long long R, int ndir,
               hipStream_t stream)
@@ -125,11 +260,25 @@ int launch_dx_k(int K, const float* dA, const float* w_pk, float* dX, const floa
 
 }  // namespace
 
+extern "C" int gmt_dx_gemm_resident(int K, int N)
+{
+    // (K, N) = (4H, H), (4H, 2H) of the H = 128 / 64 / 32 layers where N % 128 == 0, and the encoder's (H, H)
+    return ((K == 512 && (N == 128 || N == 256)) || (K == 256 && N == 128) || (K == 128 && N == 128) ||
+            (K == 256 && N == 256)) ? 1 : 0;
+}
+
 extern "C" int gmt_dx_gemm(const float* dA, const float* w_pk, float* dX, const float* act, float slope,
                            long long R, int K, int N, int ndir, hipStream_t stream)
 {
     GMT_CHECK_ARG(dA && w_pk && dX && R >= GMT_TM && (R % GMT_TM) == 0 && ndir >= 1 && ndir <= 2);
     GMT_CHECK_ARG((((uintptr_t)dA | (uintptr_t)w_pk) & 15) == 0);
+    if (gmt_dx_gemm_resident(K, N)) {
+        if (K == 512 && N == 128) return launch_dx_res<512, 128>(dA, w_pk, dX, act, slope, R, ndir, stream);
+        if (K == 512 && N == 256) return launch_dx_res<512, 256>(dA, w_pk, dX, act, slope, R, ndir, stream);
+        if (K == 256 && N == 128) return launch_dx_res<256, 128>(dA, w_pk, dX, act, slope, R, ndir, stream);
+        if (K == 256 && N == 256) return launch_dx_res<256, 256>(dA, w_pk, dX, act, slope, R, ndir, stream);
+        return launch_dx_res<128, 128>(dA, w_pk, dX, act, slope, R, ndir, stream);
+    }
     switch (N) {
         case 32: return launch_dx_k<1, 1>(K, dA, w_pk, dX, act, slope, R, ndir, stream);
         case 64: return launch_dx_k<2, 1>(K, dA, w_pk, dX, act, slope, R, ndir, stream);

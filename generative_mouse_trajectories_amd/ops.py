@@ -184,6 +184,8 @@ def _dx_shape_ok(K: int, N: int) -> bool:
 def pack_dx_weight(w_kn: torch.Tensor) -> torch.Tensor:
     """w_kn [K, N] row-major = the B operand of dX = dA . W; fragment-major for gmt_dx_gemm."""
     K, N = w_kn.shape
+    if L_.lib().gmt_dx_gemm_resident(K, N):           # the resident-weight kernel: one 32-column block per wave index
+        return _pack1(w_kn, K, K, 1 << 30, N // 32, 1, 0, N, 1)
     nw = min(4, N // 32)
     ng = N // (32 * nw)
     return _pack1(w_kn, K, K, 1 << 30, nw, ng, 32 * nw, N, 1)

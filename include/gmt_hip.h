@@ -69,8 +69,11 @@ int gmt_encoder_fwd(const float* pos, const float* dts, const float* w1_pk, cons
  * runs for RG.py:1021 / 1109 - the input gradient of an LSTM layer (dA = d(pre-activation) of both directions,
  * K = 4H, W = W_ih with its 4H axis in the buffers' unit-major order) and of the encoder's Linears with their
  * LeakyReLU backward fused (act = the layer's activated output).  dA [ndir][R][K], dX [R][N] contiguous;
- * w_pk [ndir] packed by gmt_pack_weight (K, n_waves min(4, N/32), n_gates N / (32 n_waves), gate_stride
- * 32 n_waves, stride_k N, stride_n 1).  N in {32, 64, 128, 256, 512}, K in {N, 2N, 4N} (<= 1024), R % 32 == 0. */
+ * N in {32, 64, 128, 256, 512}, K in {N, 2N, 4N} (<= 1024), R % 32 == 0.
+ * w_pk [ndir] packed by gmt_pack_weight with stride_k N, stride_n 1 and
+ *   - gmt_dx_gemm_resident(K, N) != 0 (the hot shapes: weights stay in registers): n_waves N/32, 1 gate;
+ *   - otherwise (weights streamed): n_waves min(4, N/32), n_gates N / (32 n_waves), gate_stride 32 n_waves. */
+int gmt_dx_gemm_resident(int K, int N);
 int gmt_dx_gemm(const float* dA, const float* w_pk, float* dX, const float* act, float slope,
                 long long R, int K, int N, int ndir, hipStream_t stream);
 

@@ -234,7 +234,9 @@ def test_fused_encoder_vs_oracle(ops, Hd, B, L):
 
 
 @pytest.mark.parametrize('K,N,nd,R', [(512, 256, 2, 32 * 700), (512, 128, 2, 32 * 513), (128, 128, 1, 32 * 40),
-                                       (128, 32, 2, 64), (256, 64, 1, 32 * 33), (1024, 256, 2, 32 * 20), (512, 512, 1, 32 * 9)])
+                                       (128, 32, 2, 64), (256, 64, 1, 32 * 33), (1024, 256, 2, 32 * 20), (512, 512, 1, 32 * 9),
+                                       (512, 128, 2, 32 * 3), (512, 256, 1, 32), (256, 128, 2, 32 * 300), (256, 256, 2, 32 * 129),
+                                       (128, 128, 2, 32 * 1000)])
 def test_dx_gemm_vs_fp64(ops, K, N, nd, R):
     """gmt_dx_gemm: dX = sum_d dA_d W_d, optionally times LeakyReLU'(act) - more tiles than workgroups, both
     tile-walk parities, one and two directions."""

@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 --kernel-trace --stats run: top kernels by total time."""
+"""Condenses a rocprofv3 --kernel-trace csv into the per-kernel table kept under profiles/:
+    python tools/prof_summary.py <kernel_trace.csv> [n_iterations] > profiles/rN_xx_kernel_stats.txt"""
 import csv
-import glob
 import sys
+from collections import defaultdict
 
-d = sys.argv[1]
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-f = glob.glob(d + '/**/*_kernel_stats.csv', recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
-tot = sum(float(r['TotalDurationNs']) for r in rows)
-print(f'# {f}\n# total kernel time {tot / 1e6:.2f} ms over {sum(int(r["Calls"]) for r in rows)} launches')
-print(f'{"total_ms":>10} {"calls":>7} {"avg_us":>10} {"pct":>6}  name')
-for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:n]:
-    name = r['Name']
-    name = name[:150]
-    print(f'{float(r["TotalDurationNs"]) / 1e6:10.3f} {int(r["Calls"]):7d} {float(r["AverageNs"]) / 1e3:10.1f} {float(r["Percentage"]):6.2f}  {name}')
+path = sys.argv[1]
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+tot, cnt = defaultdict(float), defaultdict(int)
+with open(path) as f:
+    for row in csv.DictReader(f):
+        name = row.get('Kernel_Name') or row.get('kernel_name')
+        dt = (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) * 1e-6
+        tot[name] += dt
+        cnt[name] += 1
+total = sum(tot.values())
+print(f'# {path}')
+print(f'# total kernel time {total:.2f} ms over {sum(cnt.values())} launches' + (f' ({iters} iterations: {total / iters:.2f} ms, {sum(cnt.values()) / iters:.0f} launches per iteration)' if iters else ''))
+print('  total_ms   calls     avg_us    pct  name')
+for name in sorted(tot, key=lambda n: -tot[n]):
+    print(f'{tot[name]:10.3f} {cnt[name]:7d} {tot[name] / cnt[name] * 1e3:10.1f} {100 * tot[name] / total:6.2f}  {name[:160]}')
