@@ -10,6 +10,11 @@ One "step" = one train_discriminator_step + one train_generator_step on a synthe
 N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL); every rank trains its own
 B=4096 shard (weak scaling) and the flat G / D gradient buffers are all-reduced once per step.
 Rank 0 prints ONE JSON line.
+
+    python bench.py --config 5 [--steps K]
+
+measures BASELINE.json configs[4] instead: generator-only sampling of 1 048 576 trajectories x 256 steps (8 launch
+groups of 131 072, one "step" each) + the f64 telemetry metric recompute of every generated point, trajectories/s.
 """
 from __future__ import annotations
 
@@ -27,7 +32,9 @@ sys.path.insert(0, ROOT)
 B_LOCAL, T_STEPS, HID, LATENT = 4096, 128, 128, 64
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_BYTES = {('lstm_fwd_fused_I2', 4096): 4.839e9}    # algorithmic: 4.328e9
+# HBM bytes per launch from the PMC passes under profiles/ (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3
+# runs): known only for the kernel / shape that was counted
+PMC_TRAFFIC_BYTES = {('lstm_fwd_fused_I2', 4096): (4.839e9, 'profiles/r1_06_pmc_lstm_fwd_I2.txt')}
 
 
 def flops_per_trajectory(T=T_STEPS, Hg=HID, Hd=HID):
@@ -51,11 +58,25 @@ def synthetic_batch(B, T, seed, device):
     return {k: v.to(device) for k, v in b.items()}
 
 
-def cpu_baseline(threads: int, B: int = 256):
-    """The CPU oracle (oracle/gan_oracle.py, pinned to the reference by tests/golden) timed on
-    this host, SURVEY.md section 8d: same synthetic batch at a reduced B, dropout on, one warm-up
-    iteration, then 4 iterations (D steps 0..3: the first carries the gradient penalty) so the GP
-    cost is amortised exactly as in the GPU metric."""
+def physical_cores() -> int:
+    """Physical cores of this host from /proc/cpuinfo (distinct (physical id, core id) pairs); 0 if unknown."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                phys = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                core = line.split(':')[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen)
+    except OSError:
+        return 0
+
+
+def _cpu_steps(threads: int, B: int, iters: int):
     from oracle import gan_oracle as O
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     import paramgen as PG
@@ -80,12 +101,106 @@ def cpu_baseline(threads: int, B: int = 256):
 
     iteration(1)                                    # warm-up (no GP)
     t0 = time.perf_counter()
-    for d_step in range(4):
+    for d_step in range(iters):
         iteration(d_step)
-    dt = time.perf_counter() - t0
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(threads: int, B: int = 256):
+    """The CPU oracle (oracle/gan_oracle.py, pinned to the reference by tests/golden) timed on
+    this host, SURVEY.md section 8d: same synthetic batch at a reduced B, dropout on, one warm-up
+    iteration, then 4 iterations (D steps 0..3: the first carries the gradient penalty) so the GP
+    cost is amortised exactly as in the GPU metric.  Also a single-thread figure on a smaller sample."""
+    dt = _cpu_steps(threads, B, 4)
+    b1 = 32
+    dt1 = _cpu_steps(1, b1, 4)
+    torch.set_num_threads(threads)
     return {'value': 4 * B / dt, 'unit': 'trajectories/s', 'cores': threads, 'kind': 'port',
-            'sample': f'oracle (plain PyTorch CPU restatement of RecurrentGAN.py:913-1118), B={B}, T={T}, H=128/128, dropout on: '
-                      f'1 warm-up + 4 iterations (D step + G step; GP on the first) in {dt:.1f}s'}
+            'sample': f'oracle (plain PyTorch CPU restatement of RecurrentGAN.py:913-1118), B={B}, T={T_STEPS}, H=128/128, dropout on: '
+                      f'1 warm-up + 4 iterations (D step + G step; GP on the first) in {dt:.1f}s on {threads} threads',
+            'single_thread': {'value': 4 * b1 / dt1, 'cores': 1,
+                              'sample': f'same, B={b1}: 1 warm-up + 4 iterations in {dt1:.1f}s'},
+            'host_physical_cores': physical_cores(), 'host_logical_cpus': os.cpu_count(),
+            'note': 'cores = torch intra-op threads used (the GPU box grants this job 16 CPUs of the host)'}
+
+
+def kernel_table(prof, steps):
+    """Per labelled kernel: launches and ms per step, achieved TFLOP/s or GB/s from the algorithmic work each call
+    declared, fraction of the matching peak."""
+    rows = {}
+    for k, (n, ms, fl, by) in prof.items():
+        r = {'launches_per_step': n / steps, 'ms_per_step': ms / steps, 'avg_launch_ms': ms / n}
+        if fl > 0:
+            r.update(bound='mfma', achieved=fl / (ms * 1e-3) / 1e12, unit='TFLOP/s')
+            r['frac'] = r['achieved'] / PEAK_F32_MFMA_TFLOPS
+        elif by > 0:
+            r.update(bound='hbm', achieved=by / (ms * 1e-3) / 1e9, unit='GB/s')
+            r['frac'] = r['achieved'] / PEAK_HBM_GBS
+        rows[k] = r
+    return rows
+
+
+def roofline_of_dominant(prof, steps, batch):
+    """The dominant kernel = the labelled HIP kernel with the largest summed duration in the timed region (ALL of
+    them are candidates: recurrent sweeps, weight-gradient and input-gradient contractions, rollouts)."""
+    rows = kernel_table(prof, steps)
+    cand = {k: r for k, r in rows.items() if 'achieved' in r}
+    if not cand:
+        return None, rows
+    name = max(cand, key=lambda k: cand[k]['ms_per_step'])
+    r = cand[name]
+    n, ms, fl, by = prof[name]
+    pmc = PMC_TRAFFIC_BYTES.get((name, batch))
+    roof = {'bound': r['bound'], 'kernel': name, 'achieved': r['achieved'],
+            'peak': PEAK_F32_MFMA_TFLOPS if r['bound'] == 'mfma' else PEAK_HBM_GBS, 'unit': r['unit'], 'frac': r['frac'],
+            'traffic': pmc[0] if pmc else None, 'traffic_unit': f'bytes/launch ({pmc[1]})' if pmc else None,
+            'avg_launch_ms': ms / n, 'launches': n,
+            'algorithmic_work_per_launch': (fl if fl > 0 else by) / n,
+            'all_kernels_ms_per_step': {k: v['ms_per_step'] for k, v in rows.items()}}
+    return roof, rows
+
+
+def bench_config5(args, dev):
+    """BASELINE.json configs[4]: 1 048 576 x 256 sampled in launch groups of 131 072 + the f64 metric recompute."""
+    import generative_mouse_trajectories_amd as gmt
+    from generative_mouse_trajectories_amd import _lib, sampling
+    cfg = gmt.Config()
+    cfg.latent_dim, cfg.generator_hidden_dim, cfg.discriminator_hidden_dim = LATENT, HID, HID
+    cfg.max_generation_steps = 256
+    torch.manual_seed(0)
+    G = gmt.Generator(cfg).to(dev).eval()
+    N, T = args.samples, 256
+    groups = args.steps if args.steps_given else (1 << 20) // N
+    g = torch.Generator().manual_seed(1234)
+    start = torch.rand(N, 2, generator=g).to(dev)
+    end = torch.rand(N, 2, generator=g).to(dev)
+    z = torch.randn(N, cfg.latent_dim, generator=g).to(dev)
+    kin = torch.empty(6, T + 1, N, device=dev, dtype=torch.float64)
+    warm = max(1, args.warmup if args.warmup_given else 1)
+    for _ in range(warm):
+        sampling.sample_and_measure(G, start, end, z, T, kin)
+    torch.cuda.synchronize()
+    _lib.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(groups):
+        sampling.sample_and_measure(G, start, end, z, T, kin)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_stop()
+    roof, rows = roofline_of_dominant(prof, groups, N)
+    out = {'metric': 'generator-only sampling + telemetry metric recompute, trajectories/s (256 steps each)',
+           'value': groups * N / dt, 'unit': 'trajectories/s', 'n_gpus': 1, 'steps': groups, 'warmup': warm,
+           'ms_per_step': dt / groups * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32 rollout / f64 metrics', 'data': 'synthetic',
+           'config': {'workload': f'BASELINE configs[4]: {groups} launch groups x {N} trajectories x {T} steps of Generator.generate '
+                                  f'(no early-stop shortcut, H_g={HID}) + mouse-telemetry kinematics in f64 on every point',
+                      'trajectories_total': groups * N, 'seq_len': T},
+           'seconds_per_1M_trajectories': dt / (groups * N) * (1 << 20),
+           'roofline': roof, 'kernels': rows,
+           'note': 'roofline.achieved of the rollout counts EXECUTED matrix FLOPs (417 152 per row-step at H=128: the '
+                   'condition term of SURVEY.md\'s 548 224 is hoisted out of the loop)',
+           'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated() / 1e9}
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -94,13 +209,21 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ['GMT_DEBUG_HANG']), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--batch', type=int, default=B_LOCAL)
+    ap.add_argument('--config', type=int, default=2, choices=(2, 5),
+                    help='BASELINE.json configs[] entry (1-based): 2 = train step, 5 = sampling + recompute')
+    ap.add_argument('--samples', type=int, default=131072, help='config 5: trajectories per launch group')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='run the two generator rollouts of an iteration one after the other')
     ap.add_argument('--cpu-threads', type=int, default=16)
     args = ap.parse_args()
+    args.steps_given, args.warmup_given = args.steps is not None, args.warmup is not None
+    if args.steps is None:
+        args.steps = 8
+    if args.warmup is None:
+        args.warmup = 8
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -108,6 +231,8 @@ def main():
     local_rank %= max(1, torch.cuda.device_count())       # (rehearsing N ranks on a one-GPU box: they share the card)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if args.config == 5:
+        return bench_config5(args, dev)
     pg = None
     force_dist = bool(os.environ.get('GMT_FORCE_DIST'))      # exercise the RCCL path with one rank
     if world > 1 or force_dist:
@@ -136,9 +261,18 @@ def main():
     batch = synthetic_batch(args.batch, T_STEPS, 1234 + rank, dev)
     tf_mask = [False] * T_STEPS                     # same host decisions on every rank
 
+    host = {'d_enqueue': 0.0, 'd_wait': 0.0, 'g_enqueue': 0.0, 'g_wait': 0.0}
+
     def one_step():
+        # host-side split of a step: time to ENQUEUE it (Python + launches) vs time blocked in the metrics read-back
+        tr.host_clock = clk = []
+        t0 = time.perf_counter()
         tr.train_discriminator_step(batch)
+        t1 = time.perf_counter()
         tr.train_generator_step(batch, {'tf_mask': tf_mask})
+        t2 = time.perf_counter()
+        host['d_enqueue'] += clk[0][1] - t0; host['d_wait'] += t1 - clk[0][1]
+        host['g_enqueue'] += clk[1][1] - t1; host['g_wait'] += t2 - clk[1][1]
 
     def barrier():
         if world > 1:
@@ -146,10 +280,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Kernel timing with HIP events perturbs what it measures (an event pair around each of the ~300 labelled calls of
+    # an iteration costs 8 % of the step), so: the last 4 warm-up iterations (one gradient-penalty period) are timed
+    # call by call - that gives the per-kernel table and names the dominant kernel - and the TIMED region carries
+    # events around the dominant kernel's launches only (roofline.achieved is measured there, as the contract asks).
+    n_tab = min(4, args.warmup)
+    for _ in range(args.warmup - n_tab):
         one_step()
+    rows, dominant = {}, 'lstm_fwd_fused_I2'
+    if n_tab:
+        barrier()
+        _lib.profile_start()
+        for _ in range(n_tab):
+            one_step()
+        barrier()
+        r0, rows = roofline_of_dominant(_lib.profile_stop(), n_tab, args.batch)
+        if r0:
+            dominant = r0['kernel']
     barrier()
-    _lib.profile_start()
+    for k in host:
+        host[k] = 0.0
+    _lib.profile_start(only=[dominant])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -166,32 +317,12 @@ def main():
         f_iter, F_G, F_D = flops_per_trajectory()
         ms = dt / args.steps * 1e3
         value = world * args.batch / (dt / args.steps)
-        # dominant kernel: the one with the largest summed duration among the HIP kernels
-        kern_flops = {  # algorithmic FLOPs per launch (2*MAC), rows = 32-padded batch of that launch
-            'lstm_fwd_fused_I1': lambda rows: 2 * 2 * rows * (T_STEPS + 1) * (4 * HID * HID + 4 * HID * HID),
-            'lstm_fwd_fused_I2': lambda rows: 2 * 2 * rows * (T_STEPS + 1) * (4 * HID * 2 * HID + 4 * HID * HID),
-            'lstm_fwd_pregates': lambda rows: 2 * 2 * rows * (T_STEPS + 1) * (4 * HID * HID),
-            'lstm_bwd': lambda rows: 2 * 2 * rows * (T_STEPS + 1) * (4 * HID * HID),
-        }
-        roof = None
-        if prof:
-            cand = {k: v for k, v in prof.items() if k in kern_flops}
-            if cand:
-                name = max(cand, key=lambda k: cand[k][1])
-                n, tot = cand[name]
-                # launches mix full-batch calls and (GP-free) half calls; use the full-batch FLOPs and the
-                # duration of an average launch of this kernel at the bench batch
-                avg_ms = tot / n
-                fl = kern_flops[name](args.batch)
-                ach = fl / (avg_ms * 1e-3) / 1e12
-                # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 on gfx950 +
-                # WRITE_SIZE, separate rocprofv3 runs): only known for the kernel / shape that was counted
-                traffic = PMC_TRAFFIC_BYTES.get((name, args.batch))
-                roof = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                        'traffic_unit': 'bytes/launch (profiles/r1_06_pmc_lstm_fwd_I2.txt)' if traffic else None,
-                        'avg_launch_ms': avg_ms, 'launches': n,
-                        'all_kernels_ms_per_step': {k: v[1] / args.steps for k, v in prof.items()}}
+        roof, _ = roofline_of_dominant(prof, args.steps, args.batch)
+        if roof:
+            roof['all_kernels_ms_per_step'] = {k: v['ms_per_step'] for k, v in rows.items()}
+            roof['note'] = ('achieved / avg_launch_ms: HIP events around this kernel only, inside the timed region; '
+                            'all_kernels_ms_per_step and "kernels": events around every labelled call during the last '
+                            f'{n_tab} warm-up iterations (timing every call slows the step by ~8 %)')
         out = {
             'metric': 'GAN trajectories/sec trained (B=4096,T=128)', 'value': value, 'unit': 'trajectories/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
@@ -205,6 +336,8 @@ def main():
             'step_tflops': value * f_iter / 1e12,
             'frac_of_f32_mfma_peak': value * f_iter / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
             'roofline': roof,
+            'kernels': rows,
+            'host_ms_per_step': {k: v / args.steps * 1e3 for k, v in host.items()},
             'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated() / 1e9,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -69,6 +69,7 @@ _SIGS = {
     'gmt_dx_gemm': [c_p, c_p, c_p, c_p, c_f, c_ll, c_i, c_i, c_i, c_p],
     'gmt_traj_from_seq': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     'gmt_traj_from_seq_bwd': [c_p, c_p, c_p, c_ll, c_ll, c_i, c_i, c_i, c_i, c_p],
+    'gmt_rollout_to_xyt_f64': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_p, c_i, c_ll, c_d, c_d, c_p],
     'gmt_gen_loss_workspace_floats': [c_i, c_p],
     'gmt_gen_loss_fwd': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     'gmt_gen_loss_bwd': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_ll, c_i, c_i, c_i, c_p],
@@ -118,35 +119,40 @@ def stream():
 
 
 # Optional per-kernel timing with events recorded on the launch stream (bench.py turns it
-# on for the timed region: roofline.achieved needs the dominant kernel's own duration).
-PROFILE = None      # None, or dict: label -> list of (start_event, end_event)
+# on for the timed region: roofline.achieved needs each kernel's own duration).  A call may state the
+# ALGORITHMIC work of its launch (flops= matrix FLOPs as 2 x MACs, nbytes= bytes an HBM-bound kernel must move);
+# profile_stop() then yields per-label totals from which the roofline table is made.
+PROFILE = None      # None, or dict: label -> list of (start_event, end_event, flops, nbytes)
+PROFILE_ONLY = None # None = every labelled call, or the set of labels to time (an event pair costs ~10 us of GPU
+                    # time and serialises neighbouring launches: timing all ~300 calls of an iteration slows it by 8 %)
 
 
-def profile_start():
-    global PROFILE
+def profile_start(only=None):
+    global PROFILE, PROFILE_ONLY
     PROFILE = {}
+    PROFILE_ONLY = set(only) if only is not None else None
 
 
 def profile_stop():
-    """Returns {label: (launches, total_ms)}; call after the stream has been synchronised."""
+    """Returns {label: (launches, total_ms, total_flops, total_bytes)}; call after the stream has been synchronised."""
     global PROFILE
     out = {}
     if PROFILE:
         for k, evs in PROFILE.items():
-            out[k] = (len(evs), sum(a.elapsed_time(b) for a, b in evs))
+            out[k] = (len(evs), sum(a.elapsed_time(b) for a, b, _, _ in evs), sum(e[2] for e in evs), sum(e[3] for e in evs))
     PROFILE = None
     return out
 
 
-def call(name, *args, label=None):
+def call(name, *args, label=None, flops=0.0, nbytes=0.0):
     fn = getattr(lib(), name)
-    if PROFILE is not None and label != 'skip':
+    if PROFILE is not None and label != 'skip' and (PROFILE_ONLY is None or (label or name) in PROFILE_ONLY):
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()
         rc = fn(*args)
         b.record()
-        PROFILE.setdefault(label or name, []).append((a, b))
+        PROFILE.setdefault(label or name, []).append((a, b, float(flops), float(nbytes)))
     else:
         rc = fn(*args)
     if rc != 0:

@@ -37,48 +37,6 @@ def kinematics_torch(pos: torch.Tensor, dts: torch.Tensor, eps: float = 1e-8) ->
                         jerk.clamp(-10000, 10000), curv.clamp(0, 100)], dim=-1)
 
 
-def _lstm_dir(x, lengths, w_ih, w_hh, b_ih, b_hh, reverse: bool):
-    L, B, _ = x.shape
-    H = w_hh.shape[1]
-    pre = F.linear(x, w_ih, b_ih + b_hh)                       # all timesteps at once
-    h = x.new_zeros(B, H)
-    c = x.new_zeros(B, H)
-    outs = [None] * L
-    w_hh_t = w_hh.t()
-    steps = torch.arange(L, device=x.device)
-    act_all = (steps[:, None] < lengths[None, :]).to(x.dtype).unsqueeze(-1)      # [L,B,1]
-    for t in (range(L - 1, -1, -1) if reverse else range(L)):
-        a = pre[t] + h @ w_hh_t
-        i, f, g, o = a.chunk(4, dim=1)
-        c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
-        h2 = torch.sigmoid(o) * torch.tanh(c2)
-        m = act_all[t]
-        h = m * h2 + (1 - m) * h
-        c = m * c2 + (1 - m) * c
-        outs[t] = m * h2
-    return torch.stack(outs, 0), h
-
-
-def discriminator_forward_torch(D, trajectories: torch.Tensor, dts: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
-    """Same mathematics as Discriminator.forward (RecurrentGAN.py:739-783), batch-first in/out."""
-    L_.require_cuda(trajectories, dts)
-    cfg = D.config
-    pos = trajectories.transpose(0, 1)
-    d = dts.transpose(0, 1)
-    lens = lengths.to(trajectories.device).clamp(min=1)
-    x = D.feature_encoder(kinematics_torch(pos, d))
-    hf = hb = None
-    nl = cfg.discriminator_num_layers
-    for l in range(nl):
-        w = D.lstm.layer_weights(l)
-        of, hf = _lstm_dir(x, lens, w[0], w[1], w[2], w[3], False)
-        ob, hb = _lstm_dir(x, lens, w[4], w[5], w[6], w[7], True)
-        x = torch.cat([of, ob], dim=-1)
-        if l + 1 < nl and D.training and cfg.lstm_dropout > 0:
-            x = F.dropout(x, cfg.lstm_dropout, True)
-    return D.output_layers(torch.cat([hf, hb], dim=-1))
-
-
 def discriminator_forward_gp(D, trajectories: torch.Tensor, dts: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
     """Twice-differentiable discriminator forward for the gradient penalty: the BiLSTM runs in
     the HIP kernels (ops.LSTMLayerGPFn: forward, first backward and the second-order sweep

@@ -59,6 +59,26 @@ void traj_from_seq_bwd_kernel(const float* __restrict__ gpos, const float* __res
     }
 }
 
+// Generated (dx, dy, dt) sequences -> the telemetry kernels' input planes: x, y in pixels and the raw time between
+// movements, f64, [T+1][n] (point 0 = the start point, dt 0) - the move from the generator's normalised fp32 output
+// to what MT.rs:550-654 consumes (BASELINE config 5: sampling + metric recompute).  Cumulative sum in f64.
+__global__ __launch_bounds__(LB)
+void rollout_to_xyt_kernel(const float* __restrict__ seq, long long sb, long long st, const float* __restrict__ starts,
+                           double* __restrict__ x, double* __restrict__ y, double* __restrict__ dt, int T, long long n,
+                           double scale_x, double scale_y)
+{
+    const long long b = (long long)blockIdx.x * LB + threadIdx.x;
+    if (b >= n) return;
+    double cx = (double)starts[2 * b], cy = (double)starts[2 * b + 1];
+    x[b] = cx * scale_x; y[b] = cy * scale_y; dt[b] = 0.0;
+    const float* s = seq + (size_t)b * sb;
+    for (int t = 0; t < T; ++t) {
+        cx += (double)s[(size_t)t * st]; cy += (double)s[(size_t)t * st + 1];
+        const size_t o = (size_t)(t + 1) * n + b;
+        x[o] = cx * scale_x; y[o] = cy * scale_y; dt[o] = (double)s[(size_t)t * st + 2];
+    }
+}
+
 struct DirTerm { float tx, ty; };
 
 __device__ __forceinline__ DirTerm target_dir(float sx, float sy, float ex, float ey)
@@ -179,6 +199,17 @@ extern "C" int gmt_traj_from_seq_bwd(const float* gpos, const float* gdts, float
                   n_rows_out <= B);
     hipLaunchKernelGGL(traj_from_seq_bwd_kernel, dim3((B + LB - 1) / LB), dim3(LB), 0, stream, gpos, gdts, gseq, stride_b,
                        stride_t, T, B, n_valid, n_rows_out);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+extern "C" int gmt_rollout_to_xyt_f64(const float* seq, long long stride_b, long long stride_t, const float* starts,
+                                      double* x, double* y, double* dt, int T, long long n, double scale_x,
+                                      double scale_y, hipStream_t stream)
+{
+    GMT_CHECK_ARG(seq && starts && x && y && dt && T >= 1 && n >= 1);
+    hipLaunchKernelGGL(rollout_to_xyt_kernel, dim3((unsigned)((n + LB - 1) / LB)), dim3(LB), 0, stream, seq, stride_b,
+                       stride_t, starts, x, y, dt, T, n, scale_x, scale_y);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }

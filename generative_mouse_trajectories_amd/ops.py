@@ -54,7 +54,7 @@ class KinematicsFn(torch.autograd.Function):
         dts = dts.contiguous().float()
         L, B = dts.shape
         feat = torch.empty(L, B, 9, device=pos.device, dtype=torch.float32)
-        L_.call('gmt_kinematics_fwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(feat), L, B, eps, L_.stream())
+        L_.call('gmt_kinematics_fwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(feat), L, B, eps, L_.stream(), nbytes=48.0 * L * B)
         ctx.save_for_backward(pos, dts)
         ctx.eps = eps
         return feat
@@ -67,7 +67,7 @@ class KinematicsFn(torch.autograd.Function):
         gpos = torch.empty_like(pos)
         gdts = torch.empty_like(dts)
         L_.call('gmt_kinematics_bwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(gfeat), L_.ptr(gpos), L_.ptr(gdts),
-                L, B, ctx.eps, L_.stream())
+                L, B, ctx.eps, L_.stream(), nbytes=60.0 * L * B)
         return gpos, gdts, None
 
 
@@ -83,12 +83,18 @@ _WEIGHTS_EPOCH = 0
 _DERIVED: dict = {}
 
 
-def weights_changed() -> None:
-    """Called by whoever writes parameters behind autograd's back (the fused Adam kernel, flat-buffer re-homing):
-    every cached derived weight is stale from here on."""
+def weights_changed(params=None) -> None:
+    """Called by whoever writes parameters behind autograd's back (the fused Adam kernel, flat-buffer re-homing,
+    checkpoint loads): cached derived weights of `params` (default: of every parameter) are stale from here on.
+    Selective, so that an optimizer step of one network does not throw away the other network's packs."""
     global _WEIGHTS_EPOCH
-    _WEIGHTS_EPOCH += 1
-    _DERIVED.clear()
+    if params is None:
+        _WEIGHTS_EPOCH += 1
+        _DERIVED.clear()
+        return
+    ids = {id(p) for p in params}
+    for key in [k for k in _DERIVED if not ids.isdisjoint(k[1:])]:
+        del _DERIVED[key]
 
 
 def derived(kind: str, tensors, build):
@@ -170,7 +176,7 @@ def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False, x_drop: Tupl
     db = torch.empty(N, device=dA.device, dtype=torch.float32) if want_db else None
     L_.call('gmt_wgrad', dA.data_ptr(), N, X.data_ptr(), X.stride(0), R, N, I, dW.data_ptr(),
             None if db is None else db.data_ptr(), 0, ws.data_ptr(), need.value, float(x_drop[0]), int(x_drop[1]),
-            L_.stream(), label=f'wgrad_N{N}_I{I}')
+            L_.stream(), label=f'wgrad_N{N}_I{I}', flops=2.0 * R * N * I)
     return dW, db
 
 
@@ -200,7 +206,7 @@ def dx_gemm(dA: torch.Tensor, w_pk: torch.Tensor, K: int, N: int, act: Optional[
     nd, R, _ = dA.shape
     dX = torch.empty(R, N, device=dA.device, dtype=torch.float32)
     L_.call('gmt_dx_gemm', L_.ptr(dA), L_.ptr(w_pk), L_.ptr(dX), L_.ptr(act), float(slope), R, K, N, nd, L_.stream(),
-            label=f'dx_gemm_K{K}_N{N}' + ('_act' if act is not None else ''))
+            label=f'dx_gemm_K{K}_N{N}' + ('_act' if act is not None else ''), flops=2.0 * nd * R * K * N)
     return dX
 
 
@@ -300,14 +306,15 @@ class LSTMLayerFn(torch.autograd.Function):
             w_ih_pk = derived('ih_pk', w_ih, lambda: pack_forward(w_ih, H, I))
             L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(w_ih_pk), L_.ptr(w_hh_pk), L_.ptr(bias),
                     L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
-                    L, B, I, H, nd, float(in_drop[0]), int(in_drop[1]), L_.stream(), label=f'lstm_fwd_fused_I{I // H}')
+                    L, B, I, H, nd, float(in_drop[0]), int(in_drop[1]), L_.stream(), label=f'lstm_fwd_fused_I{I // H}',
+                    flops=2.0 * nd * L * B * 4 * H * (I + H))
         else:
             x2 = x.view(L * B, I)
             for d in range(nd):
                 torch.addmm(gate_perm(bias[d]), x2, gate_perm(w_ih[d].detach()).t(), out=gates[d].view(L * B, 4 * H))
             L_.call('gmt_lstm_layer_fwd', None, L_.ptr(gates), None, L_.ptr(w_hh_pk), None,
                     L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
-                    L, B, I, H, nd, 0.0, 0, L_.stream(), label='lstm_fwd_pregates')
+                    L, B, I, H, nd, 0.0, 0, L_.stream(), label='lstm_fwd_pregates', flops=2.0 * nd * L * B * 4 * H * H)
         ctx.save_for_backward(x, lengths, gates, c_all, h_all, *weights)
         ctx.dims = (L, B, I, H, nd)
         ctx.drops = (in_drop, out_drop)
@@ -335,7 +342,7 @@ class LSTMLayerFn(torch.autograd.Function):
         # `gates` is overwritten in place with d(pre-activation): the graph can be back-propagated once
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
                 L_.ptr(dh_all), L_.ptr(dh_final), None, None, None, None, None, L, B, H, nd,
-                float(out_drop[0]), int(out_drop[1]), L_.stream(), label='lstm_bwd')
+                float(out_drop[0]), int(out_drop[1]), L_.stream(), label='lstm_bwd', flops=2.0 * nd * L * B * 4 * H * H)
         da = gates
         x2 = x.view(L * B, I)
         grads: List[Optional[torch.Tensor]] = []
@@ -394,7 +401,7 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         w_hh_pkT = derived('hh_pkT', w_hh, lambda: pack_transposed(w_hh, H, 4 * H))
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
                 L_.ptr(dh_all), L_.ptr(dh_final), None, None, L_.ptr(da), L_.ptr(dct), L_.ptr(dht),
-                L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp')
+                L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp', flops=2.0 * nd * L * B * 4 * H * H)
         dx = dx_from_da(da, w_ih, L * B)
         ctx.save_for_backward(gates, c_all, lengths, da, dct, dht, *w)
         ctx.dims = (L, B, I, H, nd)
@@ -416,7 +423,8 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         w_hh_pk = derived('hh_pk', w_hh, lambda: pack_forward(w_hh, H, H))
         L_.call('gmt_lstm_layer_bwd2', L_.ptr(xhat), L_.ptr(w_ih_pk), L_.ptr(w_hh_pk), L_.ptr(lengths),
                 L_.ptr(gates), L_.ptr(c_all), L_.ptr(dct), L_.ptr(dht), L_.ptr(hhat_all), L_.ptr(hhat_final),
-                L_.ptr(g_gates), L_.ptr(g_c), L, B, I, H, nd, L_.stream(), label='lstm_bwd2')
+                L_.ptr(g_gates), L_.ptr(g_c), L, B, I, H, nd, L_.stream(), label='lstm_bwd2',
+                flops=2.0 * nd * L * B * 4 * H * (I + H))
         xh2 = xhat.view(L * B, I)
         g_wih, g_whh = [], []
         for d in range(nd):
@@ -455,7 +463,7 @@ class LSTMLayerGPFn(torch.autograd.Function):
         w_hh_pk = derived('hh_pk', w_hh, lambda: pack_forward(w_hh, H, H))
         L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(w_ih_pk), L_.ptr(w_hh_pk),
                 L_.ptr(bias), L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
-                L, B, I, H, nd, 0.0, 0, L_.stream(), label=f'lstm_fwd_gp_I{I // H}')
+                L, B, I, H, nd, 0.0, 0, L_.stream(), label=f'lstm_fwd_gp_I{I // H}', flops=2.0 * nd * L * B * 4 * H * (I + H))
         ctx.save_for_backward(x, lengths, gates, c_all, h_all, *weights)
         ctx.dims = (L, B, I, H, nd)
         ctx.set_materialize_grads(False)
@@ -479,7 +487,7 @@ class LSTMLayerGPFn(torch.autograd.Function):
         w_hh_pkT = derived('hh_pkT', w_hh, lambda: pack_transposed(w_hh, H, 4 * H))
         L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
                 L_.ptr(dh_all), L_.ptr(dh_final), L_.ptr(dgates), L_.ptr(dc), L_.ptr(da), None, None,
-                L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp2')
+                L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp2', flops=2.0 * nd * L * B * 4 * H * H)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = dx_from_da(da, w_ih, L * B).view(L, B, I)
@@ -515,7 +523,7 @@ class EncoderFn(torch.autograd.Function):
         h1 = torch.empty(L, B, H, device=dev, dtype=torch.float32) if need_grad else None
         L_.call('gmt_encoder_fwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(w1_pk), L_.ptr(b1.detach().contiguous()),
                 L_.ptr(w2_pk), L_.ptr(b2.detach().contiguous()), L_.ptr(feat), L_.ptr(h1), L_.ptr(e), L, B, H,
-                float(eps), float(slope), L_.stream(), label='encoder_fwd')
+                float(eps), float(slope), L_.stream(), label='encoder_fwd', flops=2.0 * L * B * (9 * H + H * H))
         if need_grad:
             ctx.save_for_backward(pos, dts, feat, h1, e, w1, w2)
         ctx.cfg = (float(slope), float(eps), bool(grad_is_preact))
@@ -550,7 +558,7 @@ class EncoderFn(torch.autograd.Function):
                 gpos = torch.empty_like(pos)
                 gdts = torch.empty_like(dts)
                 L_.call('gmt_kinematics_bwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(gfeat), L_.ptr(gpos), L_.ptr(gdts),
-                        L, B, eps, L_.stream())
+                        L, B, eps, L_.stream(), nbytes=60.0 * L * B)
         return gpos, gdts, d_w1, d_b1, d_w2, d_b2, None, None, None
 
 
@@ -711,7 +719,7 @@ def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
     n = param.numel()
     assert grad.numel() == n and exp_avg.numel() == n and exp_avg_sq.numel() == n
     L_.call('gmt_adam_step', L_.ptr(param), L_.ptr(grad), L_.ptr(exp_avg), L_.ptr(exp_avg_sq), n,
-            lr, betas[0], betas[1], eps, step, grad_scale, L_.stream())
+            lr, betas[0], betas[1], eps, step, grad_scale, L_.stream(), nbytes=28.0 * n)
 
 
 # ----------------------------------------------------------------------------------------
@@ -805,8 +813,12 @@ class GenRolloutFn(torch.autograd.Function):
             assert not need_grad and target is None and lengths_out.dtype == torch.int32 and lengths_out.numel() == B
             a.stop_distance, a.rows_valid, a.lengths_out = float(stop_distance), int(rows_valid), lengths_out.data_ptr()
         ctx.drop = (float(dropout_p), int(seed) & 0xFFFFFFFF)
+        # executed matrix FLOPs per row-step: W_u (7 wide) + W_hh_l0 + layer 1 + head; the time-invariant
+        # condition . W_ih_l0 term (8 H^2 of SURVEY.md's 548 224 at H = 128) is hoisted out of the loop, not counted
+        g_exec = 8 * H * 7 + 8 * H * H + 16 * H * H + H * H + 3 * H
+        ctx.g_exec = g_exec
         L_.call('gmt_gen_rollout_fwd', ctypes_byref(a), L_.stream(),
-                label='gen_fwd_train' if need_grad else 'gen_fwd_nograd')
+                label='gen_fwd_train' if need_grad else 'gen_fwd_nograd', flops=float(T) * B * g_exec)
         if need_grad:
             ctx.save_for_backward(w_u, w_hh0, w_ih1, w_hh1, w1, w2, tf_mask if tf_mask is not None else torch.empty(0),
                                   *saved.values())
@@ -838,7 +850,8 @@ class GenRolloutFn(torch.autograd.Function):
         a.d_ypre = d_ypre.data_ptr(); a.d_o = d_o.data_ptr(); a.d_in0 = d_in0.data_ptr()
         a.T, a.B, a.H = T, B, H
         a.dropout_p, a.seed = ctx.drop
-        L_.call('gmt_gen_rollout_bwd', ctypes_byref(a), L_.stream())
+        L_.call('gmt_gen_rollout_bwd', ctypes_byref(a), L_.stream(), label='gen_bwd',
+                flops=float(T) * B * (ctx.g_exec - 8 * H * 7))      # the data-gradient half of the backward (dW: gmt_wgrad)
         da0 = gates0.view(T * B, 4 * H)
         da1 = gates1.view(T * B, 4 * H)
         h0v, h1v = h0.view(T * B, H), h1.view(T * B, H)

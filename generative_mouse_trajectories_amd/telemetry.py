@@ -34,7 +34,8 @@ def telemetry_kinematics(x: torch.Tensor, y: torch.Tensor, tm: torch.Tensor, len
     if lengths is not None:
         lengths = lengths.to(torch.int32).contiguous()
     L_.call('gmt_telemetry_kinematics_f64', L_.ptr(x), L_.ptr(y), L_.ptr(tm), L_.ptr(lengths), L_.ptr(kin6),
-            L_.ptr(hov), L_.ptr(tot), n_traj, n_max, int(time_is_dt), min_dt, alpha, L_.stream())
+            L_.ptr(hov), L_.ptr(tot), n_traj, n_max, int(time_is_dt), min_dt, alpha, L_.stream(),
+            nbytes=72.0 * n_traj * n_max)
     if return_aux:
         return {'kin6': kin6, 'hover_time': hov, 'total_duration': tot}
     return kin6

@@ -105,7 +105,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count += 1
         ops.adam_step_(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'], g['eps'],
                        self.step_count, self.grad_scale)
-        ops.weights_changed()                # packed / permuted copies of the parameters are stale now
+        ops.weights_changed(self.flat.params)    # packed / permuted copies of THESE parameters are stale now
         for st in self.state.values():
             st['step'] = torch.tensor(float(self.step_count))
 
@@ -383,6 +383,7 @@ class Trainer:
         self._side = None
         self._spec = None
         self._g_version = 0
+        self.host_clock = None         # a list: the step functions append (tag, perf_counter()) when a step is fully enqueued
         self.sync_replicas()
 
     # ---- helpers ---------------------------------------------------------------------
@@ -517,6 +518,8 @@ class Trainer:
         total_loss = d_loss + cfg.gradient_penalty_weight * gp
         self._backward_and_sync(total_loss, self.d_flat, self._d_sync)
         self.d_optimizer.step()
+        if self.host_clock is not None:
+            self.host_clock.append(('d_enqueued', __import__('time').perf_counter()))
         vals = torch.stack([d_loss.detach(), gp.detach(), real_score.detach().mean(), fake_score.detach().mean()]).tolist()
         return {'d_loss': vals[0], 'd_gp': vals[1], 'd_real_score': vals[2], 'd_fake_score': vals[3]}
 
@@ -577,6 +580,8 @@ class Trainer:
         self._backward_and_sync(total_loss, self.g_flat, self._g_sync)
         self.g_optimizer.step()
         self._g_version += 1
+        if self.host_clock is not None:
+            self.host_clock.append(('g_enqueued', __import__('time').perf_counter()))
         vals = torch.stack([g_loss.detach(), endpoint_loss.detach(), direction_loss.detach(),
                             fake_score.detach().mean()]).tolist()
         return {'g_loss': vals[0], 'g_endpoint_loss': vals[1], 'g_direction_loss': vals[2],

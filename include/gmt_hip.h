@@ -87,6 +87,13 @@ int gmt_traj_from_seq(const float* seq, long long stride_b, long long stride_t, 
                       float* pos, float* dts, int T, int B, int n_valid, float first_dt, hipStream_t stream);
 int gmt_traj_from_seq_bwd(const float* gpos, const float* gdts, float* gseq, long long stride_b,
                           long long stride_t, int T, int B, int n_valid, int n_rows_out, hipStream_t stream);
+/* gmt_rollout_to_xyt_f64: generated (dx, dy, dt) sequences (Generator.generate, RG.py:606-690; same strides as
+ * above) -> the telemetry kernels' f64 input planes x, y (scaled to pixels: RG.py:168-189 divides by the screen
+ * size) and raw time between movements, each [T+1][n], point 0 = the start point with dt 0 - the seam between
+ * the sampling kernel and gmt_telemetry_kinematics_f64 (time_is_dt = 1). */
+int gmt_rollout_to_xyt_f64(const float* seq, long long stride_b, long long stride_t, const float* starts,
+                           double* x, double* y, double* dt, int T, long long n, double scale_x, double scale_y,
+                           hipStream_t stream);
 /* gmt_gen_loss_fwd: every reduction of train_generator_step (RG.py:1069-1095) in one pass:
  * scal[0] = sum_b |final_b - end_b|^2 (final_b = fake_traj[b, len_b], RG.py:1072), scal[1] = sum (1 - cos) mask,
  * scal[2] = sum mask (RG.py:1077-1095), scal[3] = sum_b score_b (score may be NULL).  final_pos [n_valid][2] is

@@ -276,3 +276,46 @@ def test_train_steps_at_bench_length_vs_oracle():
         ref = gg64[k] if gg64[k] is not None else torch.zeros_like(gr).cpu()
         r32 = gg32[k] if gg32[k] is not None else torch.zeros_like(ref)
         H.assert_close(gr, ref, _tol(1e-4, r32, ref), f'G step grad {k} at T=128')
+
+
+def test_config5_sampling_and_metric_recompute_at_launch_group_size():
+    """BASELINE configs[4] at the size of one of its 8 launch groups: 131 072 trajectories x 256 steps of generator-only
+    sampling (no early-stop shortcut) + the f64 telemetry recompute of every generated point.  A slice of the sampled
+    rows against the oracle's Generator.generate restatement (RG.py:606-690, threshold 0 = never done), the pixel
+    planes against an f64 cumulative sum, and the recomputed metrics against oracle/telemetry_oracle.c (MT.rs:550-654)."""
+    from oracle import telemetry as TO
+    from generative_mouse_trajectories_amd import sampling
+    gmt, cfg, G, D = build(H.MID, 5, 6)
+    cfg.max_generation_steps = 256
+    N, Ts = 131072, 256
+    g = torch.Generator().manual_seed(11)
+    start, end = torch.rand(N, 2, generator=g), torch.rand(N, 2, generator=g)
+    z = torch.randn(N, 64, generator=g)
+    res = sampling.sample_and_measure(G, start.to(DEV), end.to(DEV), z.to(DEV), Ts)
+    assert G.training                                              # the mode it was found in is restored
+    out = res['out']
+    assert out.shape == (Ts, N, 3) and res['kin6'].shape == (6, Ts + 1, N)
+    rows = list(range(16)) + list(range(N - 16, N))
+    o_rows = out[:, rows].transpose(0, 1).cpu()
+    got = {}
+    for dt in (torch.float32, torch.float64):
+        oc, Pg, _, _ = H.oracle_models(H.MID, 5, 6, dt)
+        oc.max_generation_steps, oc.distance_threshold = Ts, 0.0
+        ref, lens = O.generator_generate(Pg, start[rows].to(dt), end[rows].to(dt), z[rows].to(dt), oc)
+        assert ref.shape == (32, Ts, 3) and int(lens.min()) == Ts
+        got[dt] = ref
+    tol = max(1e-4, 4.0 * H.relerr(got[torch.float32], got[torch.float64]))
+    H.assert_close(o_rows, got[torch.float64], tol, f'sampled rows vs the fp64 oracle at T=256 (bar {tol:.1e})')
+    # the seam: pixel planes = (start + f64 cumulative sum of the generated deltas) x screen size, dt as generated
+    x, y, dtp = (res[k][:, rows].cpu().numpy() for k in ('x', 'y', 'dt'))
+    o64 = o_rows.double().numpy()
+    cx = np.concatenate([np.zeros((32, 1)), np.cumsum(o64[:, :, 0], 1)], 1) + start[rows, 0:1].double().numpy()
+    cy = np.concatenate([np.zeros((32, 1)), np.cumsum(o64[:, :, 1], 1)], 1) + start[rows, 1:2].double().numpy()
+    assert np.array_equal(x.T, cx * cfg.screen_width) and np.array_equal(y.T, cy * cfg.screen_height)
+    assert np.array_equal(dtp.T[:, 1:], o64[:, :, 2]) and not dtp[0].any()
+    kin = res['kin6'][:, :, rows].cpu().numpy()
+    for j, r in enumerate(rows):
+        o = TO.kinematics(x[:, j].copy(), y[:, j].copy(), dtp[:, j].copy(), True)
+        for q, k in enumerate(('velocity', 'acceleration', 'jerk', 'path_length', 'direction')):
+            assert np.abs(kin[q, :, j] - o[k]).max() <= 1e-12 * max(np.abs(o[k]).max(), 1.0), (k, r)
+        assert np.abs(kin[5, :, j] - o['curvature']).max() <= 1e-9 * max(np.abs(o['curvature']).max(), 1e-300), ('curvature', r)
