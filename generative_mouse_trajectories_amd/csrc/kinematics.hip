@@ -7,89 +7,127 @@
 
 namespace {
 
-constexpr int KB = 256;        // trajectories per block
+constexpr int KB = 256;        // trajectories per block (4 waves, each with its own 64 trajectories)
 #ifndef GMT_KIN_KCH
 #define GMT_KIN_KCH 8
 #endif
-constexpr int KCH = GMT_KIN_KCH;  // consecutive timesteps per block
 
-// Block = 256 consecutive trajectories x KCH consecutive timesteps.  A thread keeps its trajectory and walks t,
-// so the 3-step look-back (look-ahead in the backward) re-reads lines this CU fetched one trip earlier instead
-// of lines 12 B * B apart in HBM, and the 9 features of the block's 256 points at one t - one contiguous run of
-// 2304 floats - go through LDS and leave (arrive) as float4.
+// Block = 256 consecutive trajectories x `kch` consecutive timesteps.  A thread keeps its trajectory and walks t,
+// so the 3-step look-back (look-ahead in the backward) re-reads lines this CU fetched one trip earlier.  The 9
+// features of a WAVE's 64 points at one t are one contiguous run of 576 floats in memory: they go through a
+// wave-private LDS region (stride-9 per-lane accesses are conflict-free) and leave / arrive as float4 - no
+// workgroup barrier anywhere, a wave only orders its own LDS accesses.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(KB)
 void kin_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ dts,
-                    float* __restrict__ feat, int L, int B, float eps)
+                    float* __restrict__ feat, int L, int B, float eps, int kch)
 {
-    __shared__ float4 stage4[KB * 9 / 4];
-    float* stage = reinterpret_cast<float*>(stage4);
-    const int b0 = blockIdx.x * KB, b = b0 + threadIdx.x;
-    const int nb = (B - b0 < KB) ? B - b0 : KB;                  // trajectories of this block
-    const int t0 = blockIdx.y * KCH, t1 = (t0 + KCH < L) ? t0 + KCH : L;
+    __shared__ float4 stage4[KB / 64][64 * 9 / 4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* stage = reinterpret_cast<float*>(stage4[wave]);
+    const int bw = blockIdx.x * KB + wave * 64;                   // first trajectory of this wave
+    if (bw >= B) return;
+    const int b = bw + lane;
+    const int nbw = (B - bw < 64) ? B - bw : 64;                  // trajectories of this wave
+    const int t0 = blockIdx.y * kch, t1 = (t0 + kch < L) ? t0 + kch : L;
     for (int t = t0; t < t1; ++t) {
-        const long long base = (long long)t * B + b0;
-        if (b < B) {
+        const long long base = (long long)t * B + bw;
+        if (lane < nbw) {
             float o[9];
-            gmt_kin::kin_fwd_vals(base + threadIdx.x, pos, dts, o, L, B, eps);
+            gmt_kin::kin_fwd_vals(base + lane, pos, dts, o, L, B, eps);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) stage[threadIdx.x * 9 + c] = o[c];      // stride 9: conflict-free
+            for (int c = 0; c < 9; ++c) stage[lane * 9 + c] = o[c];
         }
-        __syncthreads();
-        const int cnt = nb * 9;
+        wave_lds_fence();
+        const int cnt = nbw * 9;
         float* dst = feat + base * 9;
         if (((base * 9) & 3) == 0) {
-            for (int i = threadIdx.x; i * 4 < cnt; i += KB) {
-                if (i * 4 + 4 <= cnt) reinterpret_cast<float4*>(dst)[i] = stage4[i];
+            for (int i = lane; i * 4 < cnt; i += 64) {
+                if (i * 4 + 4 <= cnt) reinterpret_cast<float4*>(dst)[i] = stage4[wave][i];
                 else for (int e = i * 4; e < cnt; ++e) dst[e] = stage[e];
             }
         } else {
-            for (int e = threadIdx.x; e < cnt; e += KB) dst[e] = stage[e];
+            for (int e = lane; e < cnt; e += 64) dst[e] = stage[e];
         }
-        __syncthreads();
+        wave_lds_fence();
     }
+    (void)b;
 }
 
-// Backward: the feature gradients of steps s .. s+3 are four such runs; they sit in a ring of four LDS buffers,
-// one new run per step.
+// Backward: the feature gradients of steps s .. s+3 are four such runs; they sit in a wave-private ring of four LDS
+// regions, one new run per step, requested from HBM one step before it is staged.
 __global__ __launch_bounds__(KB)
 void kin_bwd_kernel(const float* __restrict__ pos, const float* __restrict__ dts,
                     const float* __restrict__ gfeat, float* __restrict__ gpos,
-                    float* __restrict__ gdts, int L, int B, float eps)
+                    float* __restrict__ gdts, int L, int B, float eps, int kch)
 {
-    __shared__ float4 ring4[4][KB * 9 / 4];
-    const int b0 = blockIdx.x * KB, b = b0 + threadIdx.x;
-    const int nb = (B - b0 < KB) ? B - b0 : KB;
-    const int s0 = blockIdx.y * KCH, s1 = (s0 + KCH < L) ? s0 + KCH : L;
-    auto stage_run = [&](int t) {                                // gradients of step t -> ring[t & 3] (t <= L-1)
-        const long long base = (long long)t * B + b0;
-        const int cnt = nb * 9;
-        const float* src = gfeat + base * 9;
-        float* st = reinterpret_cast<float*>(ring4[t & 3]);
-        if (((base * 9) & 3) == 0) {
-            for (int i = threadIdx.x; i * 4 < cnt; i += KB) {
-                if (i * 4 + 4 <= cnt) ring4[t & 3][i] = reinterpret_cast<const float4*>(src)[i];
-                else for (int e = i * 4; e < cnt; ++e) st[e] = src[e];
-            }
-        } else {
-            for (int e = threadIdx.x; e < cnt; e += KB) st[e] = src[e];
+    __shared__ float4 ring4[KB / 64][4][64 * 9 / 4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bw = blockIdx.x * KB + wave * 64;
+    if (bw >= B) return;
+    const int nbw = (B - bw < 64) ? B - bw : 64;
+    const int cnt = nbw * 9;
+    const int s0 = blockIdx.y * kch, s1 = (s0 + kch < L) ? s0 + kch : L;
+    const bool vec = ((((long long)B * 9) & 3) == 0) && (((long long)bw * 9 & 3) == 0) && (cnt & 3) == 0;   // every run float4-aligned
+    float4 pre[3];
+    auto fetch_run = [&](int t) {                                // gradients of step t -> registers (t <= L-1)
+        const float4* src = reinterpret_cast<const float4*>(gfeat + ((long long)t * B + bw) * 9);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = lane + 64 * j;
+            pre[j] = (i * 4 < cnt) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    for (int t = s0; t < s0 + 3 && t < L; ++t) stage_run(t);
+    auto store_run = [&](int t) {                                // registers -> ring[t & 3]
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = lane + 64 * j;
+            if (i * 4 < cnt) ring4[wave][t & 3][i] = pre[j];
+        }
+    };
+    auto stage_scalar = [&](int t) {                             // unaligned shapes: one float at a time
+        const float* src = gfeat + ((long long)t * B + bw) * 9;
+        float* st = reinterpret_cast<float*>(ring4[wave][t & 3]);
+        for (int e = lane; e < cnt; e += 64) st[e] = src[e];
+    };
+    for (int t = s0; t < s0 + 3 && t < L; ++t) {
+        if (vec) { fetch_run(t); store_run(t); } else stage_scalar(t);
+    }
+    if (vec && s0 + 3 < L) fetch_run(s0 + 3);
     for (int s = s0; s < s1; ++s) {
-        if (s + 3 < L) stage_run(s + 3);
-        __syncthreads();
-        if (b < B) {
-            const long long idx = (long long)s * B + b;
-            const float* ring = reinterpret_cast<const float*>(ring4);
-            const int tx = threadIdx.x;
+        if (s + 3 < L) {
+            if (vec) {
+                store_run(s + 3);
+                if (s + 4 < L) fetch_run(s + 4);                 // in flight under this step's arithmetic
+            } else {
+                stage_scalar(s + 3);
+            }
+        }
+        wave_lds_fence();
+        if (lane < nbw) {
+            const long long idx = (long long)s * B + bw + lane;
+            const float* ring = reinterpret_cast<const float*>(ring4[wave]);
             float gx, gy, gd;
-            gmt_kin::kin_bwd_vals(idx, pos, dts, [&](int k, int c) { return ring[((s + k) & 3) * (KB * 9) + tx * 9 + c]; },
+            gmt_kin::kin_bwd_vals(idx, pos, dts, [&](int k, int c) { return ring[((s + k) & 3) * (64 * 9) + lane * 9 + c]; },
                                   gx, gy, gd, L, B, eps);
             reinterpret_cast<float2*>(gpos)[idx] = make_float2(gx, gy);
             gdts[idx] = gd;
         }
-        __syncthreads();                                         // ring[s & 3] is overwritten by the next trip
+        wave_lds_fence();                                        // ring[s & 3] is overwritten by the next trip
     }
+}
+
+// timesteps per block: long chunks (3-step halo = 9 % at 32) when there are enough trajectories to fill the chip
+static int kin_chunk(int L, int B)
+{
+    const long long blocks32 = (long long)((B + KB - 1) / KB) * ((L + 31) / 32);
+    return blocks32 >= 1024 ? 32 : GMT_KIN_KCH;
 }
 
 }  // namespace
@@ -97,7 +135,8 @@ extern "C" int gmt_kinematics_fwd(const float* pos, const float* dts, float* fea
                                   int L, int B, float eps, hipStream_t stream)
 {
     GMT_CHECK_ARG(pos && dts && feat && L >= 1 && B >= 1);
-    hipLaunchKernelGGL(kin_fwd_kernel, dim3((B + KB - 1) / KB, (L + KCH - 1) / KCH), dim3(KB), 0, stream, pos, dts, feat, L, B, eps);
+    const int kch = kin_chunk(L, B);
+    hipLaunchKernelGGL(kin_fwd_kernel, dim3((B + KB - 1) / KB, (L + kch - 1) / kch), dim3(KB), 0, stream, pos, dts, feat, L, B, eps, kch);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }
@@ -106,8 +145,9 @@ extern "C" int gmt_kinematics_bwd(const float* pos, const float* dts, const floa
                                   float* gpos, float* gdts, int L, int B, float eps, hipStream_t stream)
 {
     GMT_CHECK_ARG(pos && dts && gfeat && gpos && gdts && L >= 1 && B >= 1);
-    hipLaunchKernelGGL(kin_bwd_kernel, dim3((B + KB - 1) / KB, (L + KCH - 1) / KCH), dim3(KB), 0, stream,
-                       pos, dts, gfeat, gpos, gdts, L, B, eps);
+    const int kch = kin_chunk(L, B);
+    hipLaunchKernelGGL(kin_bwd_kernel, dim3((B + KB - 1) / KB, (L + kch - 1) / kch), dim3(KB), 0, stream,
+                       pos, dts, gfeat, gpos, gdts, L, B, eps, kch);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }

@@ -8,16 +8,61 @@
 
 namespace {
 
-__global__ void tel_kin_kernel(const double* __restrict__ x, const double* __restrict__ y,
-                               const double* __restrict__ tm, const int* __restrict__ lengths,
-                               double* __restrict__ out6, double* __restrict__ hover, double* __restrict__ total,
-                               long long n_traj, int n_max, int time_is_dt, double min_dt, double alpha)
+// One thread per trajectory; the events are walked in chunks of TEL_C: the x / y / t of the NEXT chunk (3 x TEL_C
+// loads of 8 B per lane = 12 KB per wave) are requested before the current chunk's recurrences run, so a wave
+// always has a chunk of reads in flight under its arithmetic and stores (the dependent chain of one event is
+// ~60 f64 operations; without the staging each step waited for its own three loads).
+#ifndef GMT_TEL_C
+#define GMT_TEL_C 4
+#endif
+constexpr int TEL_C = GMT_TEL_C;
+
+__global__ __launch_bounds__(64)
+void tel_kin_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                    const double* __restrict__ tm, const int* __restrict__ lengths,
+                    double* __restrict__ out6, double* __restrict__ hover, double* __restrict__ total,
+                    long long n_traj, int n_max, int time_is_dt, double min_dt, double alpha)
 {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_traj) return;
     int len = lengths ? lengths[r] : n_max;
     len = len < 0 ? 0 : (len > n_max ? n_max : len);
-    gmt_tel::kin_traj(r, n_traj, n_max, len, x, y, tm, time_is_dt, min_dt, alpha, out6, hover, total);
+    const long long plane = (long long)n_max * n_traj;
+    gmt_tel::KinState s;
+    gmt_tel::kin_init(s);
+    double cx[TEL_C], cy[TEL_C], ct[TEL_C], nx[TEL_C], ny[TEL_C], nt[TEL_C];
+    auto fetch = [&](double (&fx)[TEL_C], double (&fy)[TEL_C], double (&ft)[TEL_C], int i0) {
+#pragma unroll
+        for (int k = 0; k < TEL_C; ++k) {
+            int i = i0 + k;
+            i = i < n_max ? i : n_max - 1;              // clamped (a harmless re-read), never branched on
+            const long long o = (long long)i * n_traj + r;
+            fx[k] = x[o]; fy[k] = y[o]; ft[k] = tm[o];
+        }
+    };
+    fetch(cx, cy, ct, 0);
+    for (int i0 = 0; i0 < n_max; i0 += TEL_C) {
+        fetch(nx, ny, nt, i0 + TEL_C);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < TEL_C; ++k) {
+            const int i = i0 + k;
+            if (i < n_max) {
+                const gmt_tel::KinOut q = gmt_tel::kin_step(s, i, i < len, cx[k], cy[k], ct[k], time_is_dt, min_dt, alpha);
+                const long long o = (long long)i * n_traj + r;
+                out6[0 * plane + o] = q.v;
+                out6[1 * plane + o] = q.a;
+                out6[2 * plane + o] = q.j;
+                out6[3 * plane + o] = q.pl;
+                out6[4 * plane + o] = q.dir;
+                out6[5 * plane + o] = q.curv;
+                if (hover) hover[o] = q.hv;
+                if (total) total[o] = q.tot;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TEL_C; ++k) { cx[k] = nx[k]; cy[k] = ny[k]; ct[k] = nt[k]; }
+    }
 }
 
 __global__ void tel_derived_kernel(const double* __restrict__ x, const double* __restrict__ y,

@@ -16,6 +16,57 @@
 
 namespace gmt_tel {
 
+// Running state of one trajectory and the update for one event (MT.rs:550-654).  kin_traj below walks a
+// trajectory with it (host simulation, simple device path); the device kernel of telemetry.hip walks the same
+// step function over register-staged chunks of events.
+struct KinState {
+    double path, v_prev, a_prev, vx_prev, vy_prev, eff_prev, hover, total, xp, yp, tp, t0;
+};
+struct KinOut { double v, a, j, pl, dir, curv, hv, tot; };
+
+GMT_HD void kin_init(KinState& s)
+{
+    s.path = s.v_prev = s.a_prev = s.vx_prev = s.vy_prev = s.eff_prev = 0.0;
+    s.hover = s.total = s.xp = s.yp = s.tp = s.t0 = 0.0;
+}
+
+// event i of a trajectory (live: i < its length; padded rows produce zeros and leave the state alone)
+GMT_HD KinOut kin_step(KinState& s, int i, bool live, double xi, double yi, double ti, int time_is_dt,
+                       double min_dt, double alpha)
+{
+    KinOut o;
+    o.v = o.a = o.j = o.pl = o.dir = o.curv = o.hv = o.tot = 0.0;
+    if (live) {
+        if (i == 0) s.t0 = ti;
+        if (i > 0) {
+            const double raw_dt = time_is_dt ? ti : ti - s.tp;               // MT.rs:580-585
+            if (time_is_dt) s.total += raw_dt; else s.total = ti - s.t0;     // MT.rs:570-574
+            const double eff = raw_dt > min_dt ? raw_dt : min_dt;            // MT.rs:587
+            const double dx = xi - s.xp, dy = yi - s.yp;                     // MT.rs:591-594
+            const double dist = sqrt(dx * dx + dy * dy);                     // MT.rs:597
+            s.path += dist;                                                  // MT.rs:600
+            const double v_raw = eff > 0.0 ? dist / eff : 0.0;               // MT.rs:603-607
+            o.v = (i == 1) ? v_raw : alpha * v_raw + (1.0 - alpha) * s.v_prev;   // MT.rs:609-613
+            const double a_raw = (i > 1 && eff > 0.0) ? (o.v - s.v_prev) / eff : 0.0;   // MT.rs:616-620
+            o.a = (i <= 1) ? a_raw : alpha * a_raw + (1.0 - alpha) * s.a_prev;   // MT.rs:622-626
+            o.j = (i > 1 && eff > 0.0) ? (o.a - s.a_prev) / eff : 0.0;       // MT.rs:629-633
+            o.dir = atan2(dy, dx);                                           // MT.rs:636
+            s.hover = (dist < 1.0) ? s.hover + raw_dt : 0.0;                 // MT.rs:638-644
+            const double vx = dx / eff, vy = dy / eff;   // curvature: RecurrentGAN.py:359-368 form
+            if (i > 1) {
+                const double dt_mid = 0.5 * (eff + s.eff_prev);
+                const double ax = (vx - s.vx_prev) / dt_mid, ay = (vy - s.vy_prev) / dt_mid;
+                const double u = vx * vx + vy * vy + 1e-8;
+                o.curv = fabs(vx * ay - vy * ax) / (u * sqrt(u));
+            }
+            s.vx_prev = vx; s.vy_prev = vy; s.eff_prev = eff; s.v_prev = o.v; s.a_prev = o.a;
+        }
+        s.xp = xi; s.yp = yi; s.tp = time_is_dt ? 0.0 : ti;
+        o.pl = s.path; o.hv = s.hover; o.tot = s.total;
+    }
+    return o;
+}
+
 // out6 planes: velocity, acceleration, jerk, path_length, direction, curvature
 // hover / total (optional, may be null): hover_time, total_duration planes.
 GMT_HD void kin_traj(long long r, long long n_traj, int n_max, int len,
@@ -23,49 +74,21 @@ GMT_HD void kin_traj(long long r, long long n_traj, int n_max, int len,
                      double min_dt, double alpha, double* out6, double* hover_out, double* total_out)
 {
     const long long plane = (long long)n_max * n_traj;
-    double path = 0.0, v_prev = 0.0, a_prev = 0.0, vx_prev = 0.0, vy_prev = 0.0, eff_prev = 0.0;
-    double hover = 0.0, total = 0.0;
-    double xp = 0.0, yp = 0.0, tp = 0.0, t0 = 0.0;
+    KinState s;
+    kin_init(s);
     for (int i = 0; i < n_max; ++i) {
         const long long o = (long long)i * n_traj + r;
-        double v = 0.0, a = 0.0, j = 0.0, dir = 0.0, curv = 0.0, pl = 0.0, hv = 0.0, tot = 0.0;
-        if (i < len) {
-            const double xi = x[o], yi = y[o], ti = tm[o];
-            if (i == 0) t0 = ti;
-            if (i > 0) {
-                const double raw_dt = time_is_dt ? ti : ti - tp;                 // MT.rs:580-585
-                if (time_is_dt) total += raw_dt; else total = ti - t0;           // MT.rs:570-574
-                const double eff = raw_dt > min_dt ? raw_dt : min_dt;            // MT.rs:587
-                const double dx = xi - xp, dy = yi - yp;                         // MT.rs:591-594
-                const double dist = sqrt(dx * dx + dy * dy);                     // MT.rs:597
-                path += dist;                                                    // MT.rs:600
-                const double v_raw = eff > 0.0 ? dist / eff : 0.0;               // MT.rs:603-607
-                v = (i == 1) ? v_raw : alpha * v_raw + (1.0 - alpha) * v_prev;   // MT.rs:609-613
-                const double a_raw = (i > 1 && eff > 0.0) ? (v - v_prev) / eff : 0.0;   // MT.rs:616-620
-                a = (i <= 1) ? a_raw : alpha * a_raw + (1.0 - alpha) * a_prev;   // MT.rs:622-626
-                j = (i > 1 && eff > 0.0) ? (a - a_prev) / eff : 0.0;             // MT.rs:629-633
-                dir = atan2(dy, dx);                                             // MT.rs:636
-                hover = (dist < 1.0) ? hover + raw_dt : 0.0;                     // MT.rs:638-644
-                const double vx = dx / eff, vy = dy / eff;   // curvature: RecurrentGAN.py:359-368 form
-                if (i > 1) {
-                    const double dt_mid = 0.5 * (eff + eff_prev);
-                    const double ax = (vx - vx_prev) / dt_mid, ay = (vy - vy_prev) / dt_mid;
-                    const double u = vx * vx + vy * vy + 1e-8;
-                    curv = fabs(vx * ay - vy * ax) / (u * sqrt(u));
-                }
-                vx_prev = vx; vy_prev = vy; eff_prev = eff; v_prev = v; a_prev = a;
-            }
-            xp = xi; yp = yi; tp = time_is_dt ? 0.0 : ti;
-            pl = path; hv = hover; tot = total;
-        }
-        out6[0 * plane + o] = v;
-        out6[1 * plane + o] = a;
-        out6[2 * plane + o] = j;
-        out6[3 * plane + o] = pl;
-        out6[4 * plane + o] = dir;
-        out6[5 * plane + o] = curv;
-        if (hover_out) hover_out[o] = hv;
-        if (total_out) total_out[o] = tot;
+        const bool live = i < len;
+        const KinOut k = kin_step(s, i, live, live ? x[o] : 0.0, live ? y[o] : 0.0, live ? tm[o] : 0.0, time_is_dt,
+                                  min_dt, alpha);
+        out6[0 * plane + o] = k.v;
+        out6[1 * plane + o] = k.a;
+        out6[2 * plane + o] = k.j;
+        out6[3 * plane + o] = k.pl;
+        out6[4 * plane + o] = k.dir;
+        out6[5 * plane + o] = k.curv;
+        if (hover_out) hover_out[o] = k.hv;
+        if (total_out) total_out[o] = k.tot;
     }
 }
 
