@@ -34,7 +34,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch from the PMC passes under profiles/ (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3
 # runs): known only for the kernel / shape that was counted
-PMC_TRAFFIC_BYTES = {('lstm_fwd_fused_I2', 4096): (4.839e9, 'profiles/r1_06_pmc_lstm_fwd_I2.txt')}
+PMC_TRAFFIC_BYTES = {('lstm_fwd_fused_I2', 4096): (4.81e9, 'profiles/r2_02_pmc_hbm.txt')}
 
 
 def flops_per_trajectory(T=T_STEPS, Hg=HID, Hd=HID):
