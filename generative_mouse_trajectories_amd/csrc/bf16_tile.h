@@ -1,0 +1,135 @@
+// Building blocks of the bf16-operand / fp32-accumulate kernels (BASELINE config 3: H = 512, where the recurrent
+// weights no longer fit a CU and the gate contractions are real dense GEMMs).
+//
+// One tile shape serves every kernel of this family: a workgroup of 4 waves computes
+//     D[p][q] = sum_k P[p][k] * Q[q][k]          256 (p) x 256 (q), K in steps of 64
+// with both operands K-CONTIGUOUS in memory (weights [N][K], activations [M][K]) - "NT" in BLAS terms.  P feeds the
+// MFMA's A side and Q its B side, so in the 32x32 accumulator tile (cdna_hip_programming.md section 3)
+//     lane l, register r  holds  D[p = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][q = l & 31]:
+// the LANE is a Q row and a register quad is FOUR CONSECUTIVE P rows.  Every kernel here puts the weights on P and
+// the activation rows (trajectory-steps) on Q, so an epilogue thread owns one trajectory row and 4 consecutive
+// output columns at a time: 8-byte bf16 / 16-byte fp32 accesses, per-row masks are per-lane scalars.
+//
+// Staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers), two LDS buffers of
+// (256 + 256) rows x 128 B, one barrier per K-tile ("glds, 2 LDS buffers, BK = 64" of the programming guide).  The
+// LDS image of a tile is [row][8 chunks of 16 B]; chunk c of row r is stored at position c ^ ((r >> 1) & 7) - the
+// DMA destination is lane-linear, so the XOR is applied to the per-lane SOURCE address - which makes the
+// ds_read_b128 fragment reads (16-lane groups {0-3,12-15,20-27}, ...) conflict-free.
+// Wave (wp, wq) = (wave >> 1, wave & 1) owns P rows [128 wp, +128) x Q rows [128 wq, +128): 4 x 4 accumulator tiles
+// (256 VGPRs), 8 fragment reads per 16 MFMAs.
+#pragma once
+#include "gmt_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace gmt_bf16 {
+
+constexpr int BK = 64;                              // k per LDS stage: one 128-byte row per operand row
+constexpr int NTHREADS = 256;
+// NPB x NQB accumulator blocks (32 x 32) per wave; the workgroup tile is (64 NPB) x (64 NQB)
+template <int NPB, int NQB> struct Tile {
+    static constexpr int TP = 64 * NPB, TQ = 64 * NQB;
+    static constexpr int STAGE_BYTES = (TP + TQ) * BK * 2;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;           // 4 x 4: 128 KiB (one workgroup per CU); 2 x 2: 64 KiB
+};
+constexpr int TP = Tile<4, 4>::TP, TQ = Tile<4, 4>::TQ, LDS_BYTES = Tile<4, 4>::LDS_BYTES;
+
+// ROWS x 64 k of a row-major bf16 operand -> LDS image at lds_tile.  g points at (tile row 0, k0); every row and
+// k-range must exist (callers check M % tile == 0, N % tile == 0, K % 64 == 0).
+template <int ROWS>
+__device__ __forceinline__ void stage(const __bf16* __restrict__ g, long long ld, char* lds_tile, int wave, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < ROWS / 32; ++j) {
+        const int row = j * 32 + wave * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const __bf16* src = g + (long long)row * ld + chunk * 8;
+        char* dst = lds_tile + (j * 32 + wave * 8) * 128;             // wave-uniform; the DMA adds lane * 16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+// acc[i][j] += P-block i (32 rows) x Q-block j (32 rows) of this wave over nk K-tiles.
+// lds: Tile::LDS_BYTES, 16-byte aligned.  No barrier after the last tile: callers that reuse the LDS put one.
+template <int NPB, int NQB>
+__device__ __forceinline__ void mainloop(const __bf16* __restrict__ Pg, long long ldp, const __bf16* __restrict__ Qg,
+                                         long long ldq, int nk, char* lds, f32x16 (&acc)[NPB][NQB], int wave, int lane)
+{
+    using T = Tile<NPB, NQB>;
+    const int wp = wave >> 1, wq = wave & 1;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int swz = (lo >> 1) & 7;
+    if (nk > 0) {
+        stage<T::TP>(Pg, ldp, lds, wave, lane);
+        stage<T::TQ>(Qg, ldq, lds + T::TP * 128, wave, lane);
+    }
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // tile t has landed; everybody is done reading the other buffer
+        char* cur = lds + (t & 1) * T::STAGE_BYTES;
+        if (t + 1 < nk) {
+            char* nxt = lds + ((t + 1) & 1) * T::STAGE_BYTES;
+            stage<T::TP>(Pg + (long long)(t + 1) * BK, ldp, nxt, wave, lane);
+            stage<T::TQ>(Qg + (long long)(t + 1) * BK, ldq, nxt + T::TP * 128, wave, lane);
+        }
+        const char* pt = cur + (wp * (T::TP / 2) + lo) * 128;
+        const char* qt = cur + T::TP * 128 + (wq * (T::TQ / 2) + lo) * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int off = ((2 * s + hi) ^ swz) << 4;
+            bf16x8 pf[NPB], qf[NQB];
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) pf[i] = *reinterpret_cast<const bf16x8*>(pt + i * 32 * 128 + off);
+#pragma unroll
+            for (int j = 0; j < NQB; ++j) qf[j] = *reinterpret_cast<const bf16x8*>(qt + j * 32 * 128 + off);
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+#pragma unroll
+                for (int j = 0; j < NQB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+template <int NPB, int NQB>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NPB][NQB])
+{
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+#pragma unroll
+        for (int j = 0; j < NQB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// fp32 -> bf16, round to nearest even (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d)
+{
+    bf16x4 v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+    return v;
+}
+
+// Tile order: blocks that run together on one XCD (blockIdx % 8) take consecutive tiles of a 4 (Q) x 8 (P) patch,
+// so the 32 CUs of an XCD share 4 activation tiles and 8 weight tiles in their L2 at any time.
+// n_p, n_q: tile counts; returns false for the blocks beyond the grid (none when the grid is exact).
+__device__ __forceinline__ void tile_of_block(long long bid, long long nblocks, int n_p, long long n_q, int& tp, long long& tq)
+{
+    long long lin = bid;
+    if ((nblocks & 7) == 0) lin = (bid & 7) * (nblocks >> 3) + (bid >> 3);
+    if ((n_q & 3) == 0) {
+        const long long per_group = 4LL * n_p;
+        const long long grp = lin / per_group, idx = lin % per_group;
+        tp = (int)(idx >> 2);
+        tq = grp * 4 + (idx & 3);
+    } else {
+        tp = (int)(lin % n_p);
+        tq = lin / n_p;
+    }
+}
+
+}  // namespace gmt_bf16

@@ -1,0 +1,252 @@
+// The recurrence of nn.LSTM (RG.py:720-727, 764-772) at hidden sizes whose recurrent weights do not fit a CU (config 3,
+// H = 512: W_hh is 2 MB in bf16): ONE LAUNCH PER TIMESTEP.  The kernel boundary is the grid-wide hand-off of h_t (every
+// workgroup of step t+1 needs all of h_t); a launch is 256-512 workgroups x ~20 us, so the ~2 us boundary is cheap, and
+// no workgroup ever waits on another inside a kernel.  Both directions of a bidirectional layer share a launch
+// (direction 0 processes t = step, direction 1 t = L-1-step).
+//
+//   forward  step:  a = pre[t] + h_prev W_hh^T   (pre = x W_ih^T + b, hoisted: gemm_bf16.hip)   -> i,f,g,o,c,h
+//   backward step:  dh = dh_out[t] + dA[t_next] W_hh + ...  -> cell backward -> dA[t] (over the saved gates, in place)
+//
+// Layouts (time-major, B % 256 == 0, H % 128 == 0):
+//   gates [L][B][ndir*4H] bf16, column of (dir d, unit u, gate g) = d*4H + (u/32)*128 + g*32 + u%32  ("slab" layout: the
+//          four gate blocks of 32 units are adjacent, so a wave's 128 weight rows are the 4 gates of its 32 units and its
+//          four accumulator blocks hold i,f,g,o of the same (row, unit) in the same lane and register);
+//   c_all [L][B][ndir*H] fp32, h_all [L][B][ndir*H] bf16 (column d*H + u);
+//   w_hh  [ndir][4H (slab order)][H] bf16;  w_hhT [ndir][H][4H (slab order)] bf16.
+// Ragged batches (lengths[b] < L): direction 0 freezes a row's state from t = len on (its h_all rows then repeat the
+// last valid h, so h_all[L-1] is the final state), direction 1 holds zero state until t = len-1 (final state =
+// h_all[0]); the backward sweep writes dA = 0 for those row-steps.
+#include "bf16_tile.h"
+
+namespace {
+
+using namespace gmt_bf16;
+
+template <bool RAGGED>
+__global__ __launch_bounds__(NTHREADS)
+void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf16* __restrict__ Hall,
+                          const __bf16* __restrict__ Whh, const int* __restrict__ lengths,
+                          int L, int B, int H, int ndir, int step, int n_mt, int n_pt)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int per_dir = n_mt * n_pt;
+    const int d = blockIdx.x / per_dir, rem = blockIdx.x % per_dir;
+    const int pt = rem % n_pt, mt = rem / n_pt;
+    const int t = d == 0 ? step : L - 1 - step;
+    const int tprev = d == 0 ? t - 1 : t + 1;
+    const bool has_prev = step > 0;
+    const long long ldg = (long long)ndir * 4 * H, ldh = (long long)ndir * H;
+    __bf16* Gt = G + (long long)t * B * ldg + (long long)d * 4 * H;
+    float* Ct = Call + (long long)t * B * ldh + (long long)d * H;
+    __bf16* Ht = Hall + (long long)t * B * ldh + (long long)d * H;
+    const float* Cp = Call + (long long)tprev * B * ldh + (long long)d * H;       // dereferenced only if has_prev
+    const __bf16* Hp = Hall + (long long)tprev * B * ldh + (long long)d * H;
+
+    f32x16 acc[4][4];
+    zero_acc<4, 4>(acc);
+    mainloop<4, 4>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H, Hp + (long long)mt * TQ * ldh, ldh,
+                   has_prev ? H / BK : 0, lds, acc, wave, lane);
+
+    const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
+    const int slab = pt * 2 + wp;                              // 32 hidden units
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = mt * TQ + wq * 128 + j * 32 + lo;
+        bool valid = true;
+        if (RAGGED) valid = t < lengths[b];
+        __bf16* gp = Gt + (long long)b * ldg + slab * 128 + 4 * hi;
+        const long long so = (long long)b * ldh + slab * 32 + 4 * hi;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            bf16x4 pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = *reinterpret_cast<const bf16x4*>(gp + g * 32 + 8 * g4);
+            f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+            if (has_prev) cp = *reinterpret_cast<const f32x4*>(Cp + so + 8 * g4);
+            float cn[4], hn[4], gi[4], gf[4], gg[4], go[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e;
+                gi[e] = gmt_sigmoid(acc[0][j][r] + (float)pre[0][e]);
+                gf[e] = gmt_sigmoid(acc[1][j][r] + (float)pre[1][e]);
+                gg[e] = gmt_tanh(acc[2][j][r] + (float)pre[2][e]);
+                go[e] = gmt_sigmoid(acc[3][j][r] + (float)pre[3][e]);
+                cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
+                hn[e] = go[e] * gmt_tanh(cn[e]);
+            }
+            if (RAGGED) {
+                if (!valid) {
+                    bf16x4 hp = pack4(0.f, 0.f, 0.f, 0.f);
+                    if (d == 0 && has_prev) hp = *reinterpret_cast<const bf16x4*>(Hp + so + 8 * g4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        cn[e] = d == 0 ? cp[e] : 0.f;
+                        hn[e] = (float)hp[e];
+                    }
+                }
+            }
+            if (!RAGGED || valid) {
+                *reinterpret_cast<bf16x4*>(gp + 0 * 32 + 8 * g4) = pack4(gi[0], gi[1], gi[2], gi[3]);
+                *reinterpret_cast<bf16x4*>(gp + 1 * 32 + 8 * g4) = pack4(gf[0], gf[1], gf[2], gf[3]);
+                *reinterpret_cast<bf16x4*>(gp + 2 * 32 + 8 * g4) = pack4(gg[0], gg[1], gg[2], gg[3]);
+                *reinterpret_cast<bf16x4*>(gp + 3 * 32 + 8 * g4) = pack4(go[0], go[1], go[2], go[3]);
+            }
+            f32x4 cv = {cn[0], cn[1], cn[2], cn[3]};
+            *reinterpret_cast<f32x4*>(Ct + so + 8 * g4) = cv;
+            *reinterpret_cast<bf16x4*>(Ht + so + 8 * g4) = pack4(hn[0], hn[1], hn[2], hn[3]);
+        }
+    }
+}
+
+// Backward step: 128 (units) x 128 (rows) tiles (K = 4H is long and the output narrow, so the smaller tile is what fills
+// the chip: 2 ndir H/128 B/128 workgroups, two per CU).
+template <bool RAGGED>
+__global__ __launch_bounds__(NTHREADS)
+void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call, const __bf16* __restrict__ dHout,
+                          const float* __restrict__ dh_fin, float* __restrict__ dc_carry, float* __restrict__ dh_carry,
+                          const __bf16* __restrict__ WhhT, const int* __restrict__ lengths,
+                          int L, int B, int H, int ndir, int step, int n_mt, int n_pt)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using T = Tile<2, 2>;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int per_dir = n_mt * n_pt;
+    const int d = blockIdx.x / per_dir, rem = blockIdx.x % per_dir;
+    const int pt = rem % n_pt, mt = rem / n_pt;
+    const int t = d == 0 ? L - 1 - step : step;
+    const int tnext = d == 0 ? t + 1 : t - 1;                  // processed by the previous launch of this sweep
+    const int tprev = d == 0 ? t - 1 : t + 1;                  // the forward pass's predecessor of t
+    const bool has_next = step > 0, has_prev = step < L - 1;
+    const long long ldg = (long long)ndir * 4 * H, ldh = (long long)ndir * H;
+    __bf16* Gt = G + (long long)t * B * ldg + (long long)d * 4 * H;
+    const __bf16* Gn = G + (long long)tnext * B * ldg + (long long)d * 4 * H;
+    const float* Ct = Call + (long long)t * B * ldh + (long long)d * H;
+    const float* Cp = Call + (long long)tprev * B * ldh + (long long)d * H;
+    const __bf16* dHt = dHout ? dHout + (long long)t * B * ldh + (long long)d * H : nullptr;
+    float* dcc = dc_carry + (long long)d * B * H;
+    float* dhc = dh_carry + (long long)d * B * H;
+    const float* dhf = dh_fin + (long long)d * B * H;
+
+    f32x16 acc[2][2];
+    zero_acc<2, 2>(acc);
+    mainloop<2, 2>(WhhT + ((long long)d * H + (long long)pt * T::TP) * 4 * H, 4LL * H, Gn + (long long)mt * T::TQ * ldg, ldg,
+                   has_next ? 4 * H / BK : 0, lds, acc, wave, lane);
+
+    const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int b = mt * T::TQ + wq * 64 + j * 32 + lo;
+        bool valid = true;
+        if (RAGGED) valid = t < lengths[b];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int slab = pt * 4 + wp * 2 + i;
+            __bf16* gp = Gt + (long long)b * ldg + slab * 128 + 4 * hi;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int u = slab * 32 + 8 * g4 + 4 * hi;     // first of 4 consecutive units
+                const long long so = (long long)b * ldh + u;
+                const long long co = (long long)b * H + u;
+                float dh[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dh[e] = acc[i][j][4 * g4 + e];
+                if (dHt) {
+                    const bf16x4 v = *reinterpret_cast<const bf16x4*>(dHt + so);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dh[e] += (float)v[e];
+                }
+                if (step == 0) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(dhf + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dh[e] += v[e];
+                }
+                f32x4 dc = {0.f, 0.f, 0.f, 0.f};
+                if (has_next) dc = *reinterpret_cast<const f32x4*>(dcc + co);
+                if (RAGGED) {
+                    if (d == 0 && has_next) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(dhc + co);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dh[e] += v[e];
+                    }
+                    if (!valid) {
+                        // frozen (direction 0) or not yet started (direction 1): no cell here; direction 0 passes dh and dc on
+                        const bf16x4 z = pack4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) *reinterpret_cast<bf16x4*>(gp + g * 32 + 8 * g4) = z;
+                        f32x4 dv = {dh[0], dh[1], dh[2], dh[3]};
+                        if (d == 0) *reinterpret_cast<f32x4*>(dhc + co) = dv;
+                        if (!has_next) *reinterpret_cast<f32x4*>(dcc + co) = dc;
+                        continue;
+                    }
+                }
+                bf16x4 gt[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gt[g] = *reinterpret_cast<const bf16x4*>(gp + g * 32 + 8 * g4);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(Ct + so);
+                f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+                if (has_prev) cp = *reinterpret_cast<const f32x4*>(Cp + so);
+                float da[4][4];
+                f32x4 dcn;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gi = (float)gt[0][e], gf = (float)gt[1][e], gg = (float)gt[2][e], go = (float)gt[3][e];
+                    const float tc = gmt_tanh(c[e]);
+                    const float dct = dc[e] + dh[e] * go * (1.f - tc * tc);
+                    da[0][e] = dct * gg * gi * (1.f - gi);
+                    da[1][e] = dct * cp[e] * gf * (1.f - gf);
+                    da[2][e] = dct * gi * (1.f - gg * gg);
+                    da[3][e] = dh[e] * tc * go * (1.f - go);
+                    dcn[e] = dct * gf;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<bf16x4*>(gp + g * 32 + 8 * g4) = pack4(da[g][0], da[g][1], da[g][2], da[g][3]);
+                *reinterpret_cast<f32x4*>(dcc + co) = dcn;
+                if (RAGGED && d == 0) {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(dhc + co) = z;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, const void* w_hh, const int* lengths,
+                                       int ragged, int L, int B, int H, int ndir, hipStream_t stream)
+{
+    GMT_CHECK_ARG(gates && c_all && h_all && w_hh && L >= 1 && (ndir == 1 || ndir == 2));
+    GMT_CHECK_ARG(B > 0 && B % TQ == 0 && H > 0 && (4 * H) % TP == 0 && H % BK == 0 && (!ragged || lengths));
+    const int n_mt = B / TQ, n_pt = 4 * H / TP;
+    auto k = ragged ? lstm_step_fwd_kernel<true> : lstm_step_fwd_kernel<false>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+        return GMT_ERR_HIP;
+    for (int step = 0; step < L; ++step)
+        hipLaunchKernelGGL(k, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), LDS_BYTES, stream, (__bf16*)gates, c_all, (__bf16*)h_all,
+                           (const __bf16*)w_hh, lengths, L, B, H, ndir, step, n_mt, n_pt);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+extern "C" int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const void* dh_out, const float* dh_fin,
+                                       float* dc_carry, float* dh_carry, const void* w_hhT, const int* lengths,
+                                       int ragged, int L, int B, int H, int ndir, hipStream_t stream)
+{
+    using T = Tile<2, 2>;
+    GMT_CHECK_ARG(gates && c_all && dh_fin && dc_carry && w_hhT && L >= 1 && (ndir == 1 || ndir == 2));
+    GMT_CHECK_ARG(B > 0 && B % 256 == 0 && H > 0 && H % T::TP == 0 && (!ragged || (lengths && dh_carry)));
+    const int n_mt = B / T::TQ, n_pt = H / T::TP;
+    auto k = ragged ? lstm_step_bwd_kernel<true> : lstm_step_bwd_kernel<false>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess)
+        return GMT_ERR_HIP;
+    for (int step = 0; step < L; ++step)
+        hipLaunchKernelGGL(k, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), T::LDS_BYTES, stream, (__bf16*)gates, c_all,
+                           (const __bf16*)dh_out, dh_fin, dc_carry, dh_carry, (const __bf16*)w_hhT, lengths, L, B, H, ndir, step,
+                           n_mt, n_pt);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}

@@ -325,6 +325,38 @@ typedef struct gmt_gen_bwd_args {
 } gmt_gen_bwd_args;
 int gmt_gen_rollout_bwd(const gmt_gen_bwd_args* args, hipStream_t stream);
 
+/* ---- bf16-operand / fp32-accumulate path (BASELINE.json configs[2]: H = 512, T = 256, "bf16 compute / fp32 accum") ----
+ * At H = 512 the recurrent weights (4H x H = 2 MB in bf16) no longer fit a CU, so this family is organised differently
+ * from the persistent fp32 kernels above: everything that does not sit on the recurrence is hoisted into dense GEMMs over
+ * all L*B row-steps, and the recurrence itself is one launch per timestep (the kernel boundary is the grid-wide hand-off
+ * of h_t).  Activations and weights are bf16 in memory, accumulators / cell state / gradients of parameters are fp32.
+ * All matrices are row-major with the contraction index contiguous; M % 256 == 0, N % 256 == 0, K % 64 == 0. */
+
+/* C[m][n] = epilogue(sum_k A[m][k] W[n][k] (+ bias[n])): nn.LSTM's x W_ih^T + b for all timesteps (RG.py:720-727), the
+ * feature encoder's Linears (RG.py:712-717, epilogue 1 = LeakyReLU) and autograd's dX = dA W (W passed transposed;
+ * epilogue 2 multiplies by LeakyReLU'(act[m][n])).  A, W, C, act: bf16; bias: fp32 or NULL. */
+int gmt_bf16_gemm_nt(const void* A, long long lda, const void* W, long long ldw, void* C, long long ldc,
+                     const float* bias, const void* act, long long ldact, int epilogue, float slope,
+                     long long M, int N, int K, hipStream_t stream);
+
+/* One bidirectional (ndir = 2) or unidirectional LSTM layer over all L timesteps, one launch per timestep (csrc/lstm_bf16.hip;
+ * nn.LSTM on the packed sequence, RG.py:720-727, 764-772).  Layouts, time-major, B % 256 == 0, H % 128 == 0:
+ *   gates [L][B][ndir*4H] bf16 - in: x W_ih^T + b_ih + b_hh from gmt_bf16_gemm_nt, out: the activated i,f,g,o; the column of
+ *         (direction d, unit u, gate g) is d*4H + (u/32)*128 + g*32 + u%32 ("slab" order; the weights' 4H axis is permuted the
+ *         same way by the caller);
+ *   c_all [L][B][ndir*H] fp32 and h_all [L][B][ndir*H] bf16 (out), column d*H + u;  w_hh [ndir][4H slab order][H] bf16.
+ * ragged != 0: lengths[b] <= L valid steps per row (direction 0 freezes the state of a finished row, so h_all[L-1] holds its
+ * final state; direction 1 starts at t = lengths[b]-1 from zero state, final state = h_all[0]). */
+int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, const void* w_hh, const int* lengths, int ragged,
+                            int L, int B, int H, int ndir, hipStream_t stream);
+/* Backward sweep of the same layer (autograd's BPTT): gates is overwritten in place with d(pre-activation) - the dA that the
+ * weight-gradient and input-gradient GEMMs then contract.  dh_out [L][B][ndir*H] bf16 or NULL: gradient of h_all from the layer
+ * above; dh_fin [ndir][B][H] fp32: gradient of the two final hidden states; dc_carry (and, for ragged batches, dh_carry)
+ * [ndir][B][H] fp32: scratch carried from launch to launch (no initialisation needed);  w_hhT [ndir][H][4H slab order] bf16. */
+int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const void* dh_out, const float* dh_fin, float* dc_carry,
+                            float* dh_carry, const void* w_hhT, const int* lengths, int ragged, int L, int B, int H,
+                            int ndir, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
