@@ -46,3 +46,7 @@ class Config:
     # that parity runs can zero them exactly as the golden-vector script does
     lstm_dropout: float = 0.1
     head_dropout: float = 0.3
+    # arithmetic of the critic's recurrent body: 'fp32' (parity configuration, H <= 256: persistent fp32-MFMA kernels) or
+    # 'bf16' (BASELINE.json configs[2]: bf16 operands, fp32 accumulation / state / master weights; H a multiple of 256;
+    # ops_bf16).  Not a reference field: the reference reaches reduced precision through torch.autocast (use_amp).
+    compute_dtype: str = 'fp32'

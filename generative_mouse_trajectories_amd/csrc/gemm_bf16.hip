@@ -88,6 +88,112 @@ int launch_nt(const __bf16* A, long long lda, const __bf16* W, long long ldw, __
     return GMT_OK;
 }
 
+// ---- weight gradients: dW[n][i] = sum_r dA[r][n] X[r][i] over the L*B row-steps ("TN": the contraction index is the
+// slow one of both operands).  The [64 r][256 col] tiles go to LDS row-major by LDS-DMA; the MFMA fragments (8 consecutive
+// r of one column per lane) come out of gfx950's transposing LDS read, ds_read_b64_tr_b16 (4 r x 16 columns per 16-lane
+// group; cdna_hip_programming.md T10).  16-byte chunk c of row r sits at c ^ ((r & 3) << 2), so the four rows a 32-lane
+// half reads (64 B each) fall on different banks.  Split over row ranges (slabs), fp32 partial sums, reduced by the caller:
+// deterministic, no float atomics.
+constexpr int WG_ROWB = 512;                                   // bytes per LDS row: 256 bf16 columns
+constexpr int WG_STAGE = 2 * BK * WG_ROWB;                     // dA tile + X tile: 64 KiB
+constexpr int WG_LDS = 2 * WG_STAGE;
+
+__device__ __forceinline__ void stage_rows(const __bf16* __restrict__ g, long long ld, char* lds_tile, int wave, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < BK / 8; ++j) {                          // 8 rows (4 waves x 2) per round
+        const int row = j * 8 + wave * 2 + (lane >> 5);
+        const int chunk = (lane & 31) ^ ((row & 3) << 2);
+        const __bf16* src = g + (long long)row * ld + chunk * 8;
+        char* dst = lds_tile + (j * 8 + wave * 2) * WG_ROWB;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// fragment of column block cb (32 columns) for k-step s (16 rows): lane (lo, hi) gets rows 16 s + 8 hi + 0..7 of column lo
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int col0, int s, int lane)
+{
+    const int grp = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int col = col0 + 16 * (grp & 1) + 4 * p;             // first of the 4 columns this lane addresses
+    const int chunk = col >> 3, sub = (col & 7) * 2;
+    s16x4 h[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row = 16 * s + 8 * (grp >> 1) + 4 * half + q;
+        const char* a = tile + row * WG_ROWB + ((chunk ^ ((row & 3) << 2)) << 4) + sub;
+        h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
+    }
+    s16x8 v = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(NTHREADS)
+void wgrad_tn_kernel(const __bf16* __restrict__ dA, long long lda, const __bf16* __restrict__ X, long long ldx,
+                     float* __restrict__ slabs, long long M, int N, int I, int n_p, int n_q, long long rows_per_slab)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // slabs of one row range on one XCD (blockIdx % 8): its dA / X rows are shared by the tiles in that L2
+    const int tiles = n_p * n_q;
+    const int slab = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int tp = tile % n_p, tq = tile / n_p;
+    const long long r0 = slab * rows_per_slab;
+    long long r1 = r0 + rows_per_slab;
+    if (r1 > M) r1 = M;
+    const int nk = r1 > r0 ? (int)((r1 - r0) / BK) : 0;
+    const __bf16* Ag = dA + r0 * lda + (long long)tp * 256;
+    const __bf16* Xg = X + r0 * ldx + (long long)tq * 256;
+
+    f32x16 acc[4][4];
+    zero_acc<4, 4>(acc);
+    const int wp = wave >> 1, wq = wave & 1;
+    if (nk > 0) {
+        stage_rows(Ag, lda, lds, wave, lane);
+        stage_rows(Xg, ldx, lds + BK * WG_ROWB, wave, lane);
+    }
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* cur = lds + (t & 1) * WG_STAGE;
+        if (t + 1 < nk) {
+            char* nxt = lds + ((t + 1) & 1) * WG_STAGE;
+            stage_rows(Ag + (long long)(t + 1) * BK * lda, lda, nxt, wave, lane);
+            stage_rows(Xg + (long long)(t + 1) * BK * ldx, ldx, nxt + BK * WG_ROWB, wave, lane);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 pf[4], qf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[i] = tr_frag(cur, wp * 128 + i * 32, s, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qf[j] = tr_frag(cur + BK * WG_ROWB, wq * 128 + j * 32, s, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int lo = lane & 31, hi = lane >> 5;
+    float* out = slabs + (long long)slab * N * I;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = tq * 256 + wq * 128 + j * 32 + lo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = tp * 256 + wp * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                out[(long long)n * I + col] = acc[i][j][r];
+            }
+        }
+}
+
 }  // namespace
 
 extern "C" int gmt_bf16_gemm_nt(const void* A, long long lda, const void* W, long long ldw, void* C, long long ldc,
@@ -105,4 +211,19 @@ extern "C" int gmt_bf16_gemm_nt(const void* A, long long lda, const void* W, lon
         case 1: return launch_nt<1>(a, lda, w, ldw, c, ldc, bias, ac, ldact, slope, M, N, K, stream);
         default: return launch_nt<2>(a, lda, w, ldw, c, ldc, bias, ac, ldact, slope, M, N, K, stream);
     }
+}
+
+extern "C" int gmt_bf16_wgrad_tn(const void* dA, long long lda, const void* X, long long ldx, float* slabs,
+                                 long long M, int N, int I, int n_slabs, hipStream_t stream)
+{
+    GMT_CHECK_ARG(dA && X && slabs && M > 0 && N > 0 && I > 0 && n_slabs >= 1);
+    GMT_CHECK_ARG(M % BK == 0 && N % 256 == 0 && I % 256 == 0 && lda >= N && ldx >= I && (lda % 8) == 0 && (ldx % 8) == 0);
+    if (hipFuncSetAttribute((const void*)wgrad_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS) != hipSuccess)
+        return GMT_ERR_HIP;
+    const int n_p = N / 256, n_q = I / 256;
+    long long rows_per_slab = ((M / BK + n_slabs - 1) / n_slabs) * BK;
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)(n_p * n_q * n_slabs)), dim3(NTHREADS), WG_LDS, stream,
+                       (const __bf16*)dA, lda, (const __bf16*)X, ldx, slabs, M, N, I, n_p, n_q, rows_per_slab);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
 }

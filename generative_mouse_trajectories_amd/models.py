@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from . import _lib as L_
 from . import ops
+from . import ops_bf16
 from .config import Config
 
 
@@ -239,8 +240,12 @@ class Discriminator(nn.Module):
         super().__init__()
         self.config = config
         H = config.discriminator_hidden_dim
-        if H % 32 != 0 or H > 256:
-            raise NotImplementedError('discriminator_hidden_dim must be a multiple of 32, at most 256')
+        self.bf16 = getattr(config, 'compute_dtype', 'fp32') == 'bf16'
+        if self.bf16:
+            if H % 256 != 0 or H > 1024:
+                raise NotImplementedError('compute_dtype bf16: discriminator_hidden_dim must be a multiple of 256, at most 1024')
+        elif H % 32 != 0 or H > 256:
+            raise NotImplementedError("discriminator_hidden_dim must be a multiple of 32, at most 256 (larger: compute_dtype = 'bf16')")
         self.feature_encoder = nn.Sequential(SNLinear(9, H), nn.LeakyReLU(0.2), SNLinear(H, H), nn.LeakyReLU(0.2))
         self.lstm = _LSTMParams(H, H, config.discriminator_num_layers, True)
         self.output_layers = nn.Sequential(SNLinear(2 * H, H), nn.LeakyReLU(0.2), nn.Dropout(config.head_dropout),
@@ -274,6 +279,15 @@ class Discriminator(nn.Module):
         # expects that
         fe = self.feature_encoder
         slope = float(fe[1].negative_slope)
+        if self.bf16:
+            # config 3: hoisted bf16 GEMMs + one launch per timestep (ops_bf16); no inter-layer dropout on this path yet
+            if self.training and float(self.config.lstm_dropout) > 0:
+                raise NotImplementedError("compute_dtype bf16 runs with lstm_dropout = 0 (the fused mask is not built for this path)")
+            w1, w2 = sn_w.pop(0), sn_w.pop(0)
+            lw = [w for l in range(self.config.discriminator_num_layers) for w in self.lstm.layer_weights(l)]
+            h_final = ops_bf16.critic_body(pos_tm, dts_tm, lengths_i32, slope, 1e-8, self.config.discriminator_num_layers,
+                                           w1, fe[0].bias, w2, fe[2].bias, lw)
+            return self.run_sequential(self.output_layers, h_final, sn_w)
         fused_enc = self.fuse_input_gemm and fe[3].negative_slope == fe[1].negative_slope
         if fused_enc:
             w1, w2 = sn_w.pop(0), sn_w.pop(0)
@@ -303,6 +317,8 @@ class Discriminator(nn.Module):
         L_.require_cuda(trajectories, dts)
         B = trajectories.shape[0]
         Bp = ops.pad_rows(B)
+        if self.bf16:
+            Bp = (B + ops_bf16.ROW_TILE - 1) // ops_bf16.ROW_TILE * ops_bf16.ROW_TILE
         pos_tm = _pad_batch(trajectories.transpose(0, 1), Bp, 1).contiguous()
         dts_tm = _pad_batch(dts.transpose(0, 1), Bp, 1).contiguous()
         lens = _pad_batch(lengths.to(device=trajectories.device, dtype=torch.int32).clamp(min=1), Bp, 0, 1)

@@ -1,0 +1,219 @@
+"""Host side of the bf16-operand / fp32-accumulate path (BASELINE.json configs[2]: H = 512, T = 256).
+
+At H = 512 the recurrent weights of one LSTM direction are 2 MB in bf16 - they fit neither the register file nor the LDS
+of a CU, so the persistent one-workgroup-per-32-rows kernels of `ops` do not apply.  This path instead
+  * hoists everything that is not on the recurrence into dense bf16 GEMMs over all L*B row-steps
+    (x W_ih^T + b of both directions, the feature encoder, every dX and every dW): `gmt_bf16_gemm_nt`, `gmt_bf16_wgrad_tn`;
+  * runs the recurrence as one launch per timestep (`gmt_bf16_lstm_layer_fwd/bwd`), the kernel boundary being the
+    grid-wide hand-off of h_t;
+  * keeps activations and weights in bf16, accumulators / cell state / parameter gradients / master weights in fp32.
+The critic body (kinematics -> feature encoder -> BiLSTM stack -> final hidden states, RG.py:757-778) is ONE autograd
+Function so that the big buffers are reused in place (gates -> d(pre-activation)).
+
+Not covered yet (documented in DESIGN.md section 7): the gradient penalty's double backward and the generator at H = 512;
+the inter-layer dropout of nn.LSTM (this path runs with lstm_dropout = 0)."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _lib as L_
+from . import ops
+
+ROW_TILE = 256          # rows per workgroup tile of every bf16 kernel: batches are padded to a multiple of it
+BF16 = torch.bfloat16
+
+_PERMS: dict = {}
+
+
+def slab_perm(H: int, device) -> torch.Tensor:
+    """Row order of a [4H] gate axis in the kernels' slab layout: position s*128 + g*32 + u  <-  torch row g*H + 32 s + u."""
+    key = (H, str(device))
+    if key not in _PERMS:
+        c = torch.arange(4 * H, device=device)
+        s, g, u = c // 128, (c % 128) // 32, c % 32
+        _PERMS[key] = g * H + s * 32 + u
+    return _PERMS[key]
+
+
+def slab_unperm_rows(w: torch.Tensor, H: int) -> torch.Tensor:
+    """Inverse of indexing the first axis with slab_perm: slab-ordered rows -> torch's gate-major rows."""
+    out = torch.empty_like(w)
+    out[slab_perm(H, w.device)] = w
+    return out
+
+
+def gemm_nt(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[torch.Tensor] = None,
+            epilogue: int = 0, slope: float = 0.2, label: Optional[str] = None) -> torch.Tensor:
+    """C = epilogue(A W^T + bias): A [M, K] bf16 (row stride >= K), W [N, K] bf16 -> [M, N] bf16."""
+    M, K = A.shape
+    N = W.shape[0]
+    L_.require_cuda(A, W)
+    assert A.dtype == BF16 and W.dtype == BF16 and A.stride(1) == 1 and W.stride(1) == 1 and W.shape[1] == K
+    assert act is None or (act.dtype == BF16 and act.stride(1) == 1 and act.shape == (M, N))
+    C = torch.empty(M, N, device=A.device, dtype=BF16)
+    L_.call('gmt_bf16_gemm_nt', A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), L_.ptr(C), N,
+            L_.ptr(bias) if bias is not None else None, act.data_ptr() if act is not None else None,
+            act.stride(0) if act is not None else 0, int(epilogue), float(slope), M, N, K, L_.stream(),
+            label=label or f'bf16_gemm_N{N}_K{K}', flops=2.0 * M * N * K)
+    return C
+
+
+def wgrad_tn(dA: torch.Tensor, X: torch.Tensor, label: Optional[str] = None) -> torch.Tensor:
+    """dA^T X in fp32: dA [M, N], X [M, I] bf16 views (row strides free) -> [N, I]."""
+    M, N = dA.shape
+    I = X.shape[1]
+    assert dA.dtype == BF16 and X.dtype == BF16 and dA.stride(1) == 1 and X.stride(1) == 1 and X.shape[0] == M
+    tiles = (N // 256) * (I // 256)
+    n_slabs = max(1, min(64, (768 + tiles - 1) // tiles, M // 4096 if M >= 4096 else 1))
+    slabs = torch.empty(n_slabs, N, I, device=dA.device, dtype=torch.float32)
+    L_.call('gmt_bf16_wgrad_tn', dA.data_ptr(), dA.stride(0), X.data_ptr(), X.stride(0), L_.ptr(slabs), M, N, I, n_slabs,
+            L_.stream(), label=label or f'bf16_wgrad_N{N}_I{I}', flops=2.0 * M * N * I)
+    return slabs[0] if n_slabs == 1 else slabs.sum(0)
+
+
+def lstm_layer_weights(weights: List[torch.Tensor], H: int, nd: int):
+    """bf16 forms of one layer's parameters (cached until the parameters change, ops.derived):
+    wih [nd*4H, I] (slab-ordered rows, directions stacked), bias [nd*4H] fp32 (b_ih + b_hh), whh [nd, 4H, H],
+    whhT [nd, H, 4H], wihT [I, nd*4H] (for dX = dA wihT^T)."""
+    def build():
+        p = slab_perm(H, weights[0].device)
+        wih = torch.cat([weights[4 * d][p] for d in range(nd)], 0)
+        bias = torch.cat([(weights[4 * d + 2] + weights[4 * d + 3])[p] for d in range(nd)], 0).float().contiguous()
+        whh = torch.stack([weights[4 * d + 1][p] for d in range(nd)], 0)
+        return (wih.to(BF16).contiguous(), bias, whh.to(BF16).contiguous(), whh.transpose(1, 2).to(BF16).contiguous(),
+                wih.t().to(BF16).contiguous())
+    return ops.derived('bf16_lstm_layer', [w for w in weights], build)
+
+
+class CriticBodyBf16Fn(torch.autograd.Function):
+    """pos [L,B,2], dts [L,B] fp32 (time-major, B % 256 == 0), lengths int32 [B], the two (spectrally normalised) encoder
+    Linears and the LSTM parameters (per layer and direction: w_ih, w_hh, b_ih, b_hh) -> h_final [B, 2H] fp32
+    (final hidden state of the last layer, forward | reverse: RG.py:776-778)."""
+
+    @staticmethod
+    def forward(ctx, pos, dts, lengths, slope, eps, n_layers, w1, b1, w2, b2, *lw):
+        L_.require_cuda(pos, dts, w1, w2)
+        pos, dts = pos.contiguous().float(), dts.contiguous().float()
+        L, B = dts.shape
+        H = w1.shape[0]
+        nd = 2
+        if B % ROW_TILE or H % 256 or w1.shape != (H, 9) or w2.shape != (H, H) or len(lw) != 4 * nd * n_layers:
+            raise L_.GmtError(f'bf16 critic body: B={B} must be a multiple of {ROW_TILE}, H={H} of 256')
+        dev = pos.device
+        M = L * B
+        lengths = lengths.contiguous()
+        ragged = bool((lengths.min() < L).item())
+        need_grad = any(ctx.needs_input_grad)
+        # kinematic features, zero-padded to one 64-wide K tile
+        feat = torch.empty(L, B, 9, device=dev, dtype=torch.float32)
+        L_.call('gmt_kinematics_fwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(feat), L, B, float(eps), L_.stream(), nbytes=48.0 * M)
+        # The first Linear's K is 9, its K tile 64: the spare slots carry the bf16 round-off of the features and of the
+        # weights (x = x_hi + x_lo, w = w_hi + w_lo; slots 0-8 x_hi w_hi, 9-17 x_lo w_hi, 18-26 x_hi w_lo), so that layer
+        # is computed to ~16 bits at no cost - the raw features span 1e-4 ... 1e4 (clamped jerk), too wide for 8 bits.
+        f2 = feat.view(M, 9)
+        f_hi = f2.to(BF16)
+        feat64 = torch.zeros(M, 64, device=dev, dtype=BF16)
+        feat64[:, 0:9] = f_hi
+        feat64[:, 9:18] = (f2 - f_hi.float()).to(BF16)
+        feat64[:, 18:27] = f_hi
+        w1d = w1.detach().float()
+        w_hi = w1d.to(BF16)
+        w1p = torch.zeros(H, 64, device=dev, dtype=BF16)
+        w1p[:, 0:9] = w_hi
+        w1p[:, 9:18] = w_hi
+        w1p[:, 18:27] = (w1d - w_hi.float()).to(BF16)
+        w2b = w2.detach().to(BF16).contiguous()
+        h1 = gemm_nt(feat64, w1p, b1.detach().float().contiguous(), None, 1, slope, label='bf16_enc1')
+        x = gemm_nt(h1, w2b, b2.detach().float().contiguous(), None, 1, slope, label='bf16_enc2')
+        saved_layers = []
+        for l in range(n_layers):
+            ws = list(lw[4 * nd * l: 4 * nd * (l + 1)])
+            wih, bias, whh, whhT, wihT = lstm_layer_weights(ws, H, nd)
+            G = gemm_nt(x, wih, bias, None, 0, 0.0, label=f'bf16_pre_l{l}')                  # [M, nd*4H]
+            c_all = torch.empty(M, nd * H, device=dev, dtype=torch.float32)
+            h_all = torch.empty(M, nd * H, device=dev, dtype=BF16)
+            L_.call('gmt_bf16_lstm_layer_fwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(whh), L_.ptr(lengths),
+                    int(ragged), L, B, H, nd, L_.stream(), label='bf16_lstm_fwd', flops=2.0 * (L - 1) * B * nd * 4 * H * H)
+            saved_layers.append((x, G, c_all, h_all))
+            x = h_all
+        h_final = torch.cat([x[(L - 1) * B:, :H], x[:B, H:]], 1).float()
+        if need_grad:
+            ctx.save_for_backward(pos, dts, lengths, feat, w1, w2, *lw)
+            ctx.bufs = (feat64, h1, saved_layers)
+        ctx.cfg = (float(slope), float(eps), int(n_layers), ragged, L, B, H, nd)
+        return h_final
+
+    @staticmethod
+    def backward(ctx, dh_final):
+        if ctx.bufs is None:
+            raise L_.GmtError('bf16 critic body: backward called twice (the saved gate buffers were consumed in place)')
+        pos, dts, lengths, feat, w1, w2, *lw = ctx.saved_tensors
+        feat64, h1, saved_layers = ctx.bufs
+        ctx.bufs = None
+        slope, eps, n_layers, ragged, L, B, H, nd = ctx.cfg
+        dev = pos.device
+        M = L * B
+        need = ctx.needs_input_grad
+        need_in = need[0] or need[1]
+        need_w1, need_w2 = need[6] or need[7], need[8] or need[9]
+        need_lw = any(need[10:])
+        dh_final = dh_final.contiguous().float()
+        dh_fin = torch.stack([dh_final[:, :H], dh_final[:, H:]], 0).contiguous()
+        dcc = torch.empty(nd, B, H, device=dev, dtype=torch.float32)
+        dhc = torch.empty(nd, B, H, device=dev, dtype=torch.float32) if ragged else None
+        grads_lw: List[Optional[torch.Tensor]] = [None] * len(lw)
+        dh_out = None
+        for l in range(n_layers - 1, -1, -1):
+            x, G, c_all, h_all = saved_layers[l]
+            ws = list(lw[4 * nd * l: 4 * nd * (l + 1)])
+            wih, bias, whh, whhT, wihT = lstm_layer_weights(ws, H, nd)
+            L_.call('gmt_bf16_lstm_layer_bwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(dh_out), L_.ptr(dh_fin), L_.ptr(dcc),
+                    L_.ptr(dhc), L_.ptr(whhT), L_.ptr(lengths), int(ragged), L, B, H, nd, L_.stream(),
+                    label='bf16_lstm_bwd', flops=2.0 * (L - 1) * B * nd * 4 * H * H)
+            dA = G                                                                             # [M, nd*4H] d(pre-activation)
+            if need_lw:
+                p = slab_perm(H, dev)
+                d_wih = wgrad_tn(dA, x, label=f'bf16_wgrad_ih_l{l}')                           # [nd*4H, I]
+                db = dA.sum(0, dtype=torch.float32)
+                for d in range(nd):
+                    cols = slice(d * 4 * H, (d + 1) * 4 * H)
+                    if d == 0:      # h_prev of row-step r is h_all[r - B]
+                        d_whh = wgrad_tn(dA[B:, cols], h_all[:M - B, :H], label='bf16_wgrad_hh')
+                    else:           # reverse direction: h_prev is h_all[r + B]
+                        d_whh = wgrad_tn(dA[:M - B, cols], h_all[B:, H:], label='bf16_wgrad_hh')
+                    k = 4 * nd * l + 4 * d
+                    grads_lw[k] = slab_unperm_rows(d_wih[cols], H)
+                    grads_lw[k + 1] = slab_unperm_rows(d_whh, H)
+                    grads_lw[k + 2] = slab_unperm_rows(db[cols], H)
+                    grads_lw[k + 3] = grads_lw[k + 2]
+            if l > 0:
+                dh_out = gemm_nt(dA, wihT, None, None, 0, 0.0, label=f'bf16_dx_l{l}')         # [M, nd*H]
+                dh_fin = torch.zeros_like(dh_fin)            # only the last layer's final states reach the head
+            saved_layers[l] = None
+        g_w1 = g_b1 = g_w2 = g_b2 = gpos = gdts = None
+        if need_in or need_w1 or need_w2:
+            e = x                                                                              # layer 0's input
+            d_pre2 = gemm_nt(dA, wihT, None, e, 2, slope, label='bf16_dx_l0')                 # [M, H], LeakyReLU'(e) applied
+            del dA, G
+            if need_w2:
+                g_w2 = wgrad_tn(d_pre2, h1, label='bf16_wgrad_enc2')
+                g_b2 = d_pre2.sum(0, dtype=torch.float32)
+            if need_in or need_w1:
+                w2T = w2.detach().t().to(BF16).contiguous()
+                d_pre1 = gemm_nt(d_pre2, w2T, None, h1, 2, slope, label='bf16_dx_enc2')       # [M, H]
+                if need_w1:
+                    gw = torch.mm(d_pre1.t(), feat64[:, :18]).float()                          # K = 9: 0.1 % of the FLOPs
+                    g_w1 = (gw[:, :9] + gw[:, 9:18]).contiguous()                              # x_hi + x_lo
+                    g_b1 = d_pre1.sum(0, dtype=torch.float32)
+                if need_in:
+                    gfeat = torch.mm(d_pre1, w1.detach().to(BF16)).float().contiguous()        # [M, 9]
+                    gpos, gdts = torch.empty_like(pos), torch.empty_like(dts)
+                    L_.call('gmt_kinematics_bwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(gfeat), L_.ptr(gpos), L_.ptr(gdts),
+                            L, B, eps, L_.stream(), nbytes=60.0 * M)
+        return (gpos, gdts, None, None, None, None, g_w1, g_b1, g_w2, g_b2, *grads_lw)
+
+
+def critic_body(pos, dts, lengths_i32, slope, eps, n_layers, w1, b1, w2, b2, lstm_weights):
+    return CriticBodyBf16Fn.apply(pos, dts, lengths_i32, slope, eps, n_layers, w1, b1, w2, b2, *lstm_weights)

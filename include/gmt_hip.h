@@ -357,6 +357,12 @@ int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const void* dh_out,
                             float* dh_carry, const void* w_hhT, const int* lengths, int ragged, int L, int B, int H,
                             int ndir, hipStream_t stream);
 
+/* Weight gradients of the bf16 path: slabs[s][n][i] = sum over the s-th of n_slabs row ranges of dA[r][n] * X[r][i]
+ * (autograd's dW = dA^T X for the LSTM and encoder weights; the caller sums the n_slabs fp32 partial results - deterministic).
+ * dA [M][lda], X [M][ldx] bf16; M % 64 == 0, N % 256 == 0, I % 256 == 0. */
+int gmt_bf16_wgrad_tn(const void* dA, long long lda, const void* X, long long ldx, float* slabs,
+                      long long M, int N, int I, int n_slabs, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

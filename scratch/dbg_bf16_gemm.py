@@ -44,3 +44,25 @@ for (M, N, K) in [(4096 * 64, 4096, 512), (4096 * 64, 4096, 1024), (4096 * 64, 5
     e1.record(); torch.cuda.synchronize()
     t2 = e0.elapsed_time(e1) / 5 * 1e-3
     print(f'M={M} N={N} K={K}: {t*1e3:.3f} ms = {2*M*N*K/t/1e12:.0f} TFLOP/s   (torch/hipBLASLt {2*M*N*K/t2/1e12:.0f})')
+
+def wgrad(dA, X, S):
+    M, N = dA.shape; I = X.shape[1]
+    slabs = torch.empty(S, N, I, device=dev)
+    L_.call('gmt_bf16_wgrad_tn', L_.ptr(dA), dA.stride(0), L_.ptr(X), X.stride(0), L_.ptr(slabs), M, N, I, S, L_.stream())
+    return slabs.sum(0)
+
+for (M, N, I, S) in [(64, 256, 256, 1), (640, 512, 256, 3), (8192, 256, 512, 4)]:
+    dA = torch.randn(M, N, device=dev).bfloat16(); X = torch.randn(M, I, device=dev).bfloat16()
+    ref = dA.float().t() @ X.float()
+    got = wgrad(dA, X, S)
+    print(f'wgrad M={M} N={N} I={I} S={S}: max rel err {((got - ref).abs().max() / ref.abs().max()).item():.2e}')
+for (M, N, I, S) in [(4096 * 64, 4096, 512, 8), (4096 * 64, 4096, 1024, 4), (4096 * 64, 2048, 512, 16)]:
+    dA = torch.randn(M, N, device=dev).bfloat16(); X = torch.randn(M, I, device=dev).bfloat16()
+    for _ in range(2): wgrad(dA, X, S)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3): wgrad(dA, X, S)
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / 3 * 1e-3
+    print(f'wgrad M={M} N={N} I={I} S={S}: {t*1e3:.3f} ms = {2*M*N*I/t/1e12:.0f} TFLOP/s')
