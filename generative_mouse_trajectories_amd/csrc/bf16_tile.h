@@ -114,6 +114,74 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d)
     return v;
 }
 
+// ---- epilogue tiles through LDS.  In the accumulator layout a lane owns ONE row (trajectory) and 4 consecutive columns,
+// so a direct global access is 8-16 bytes per lane, each lane on a different row: a 128-byte line is fetched or written
+// in 8-16 separate requests, and the L2 takes ~16 requests per clock per XCD whatever their size (measured: the GEMM's
+// tile store sped up 5.5 us when its 8 192 sixteen-byte requests became 1 024 full lines).  The kernels therefore move
+// their epilogue operands as whole rows - LDS-DMA in, 16 bytes per lane out - and pick their elements out of the LDS.
+// Image of a [rows][ROWB bytes] block: lane-linear (the DMA's rule), the 16-byte chunk c of row r stored at position
+// c ^ (r & (ROWB/16 - 1)), so that lanes on consecutive rows reading the same column hit different banks.
+template <int ROWB> struct RowImage {
+    static constexpr int CH = ROWB / 16;                 // chunks per row (8, 16 or 32)
+    static constexpr int RPI = 64 / CH;                  // rows per wave-instruction
+    static __device__ __forceinline__ int addr(int row, int byte_off) {
+        return row * ROWB + ((((byte_off >> 4) ^ row) & (CH - 1)) << 4) + (byte_off & 15);
+    }
+    // rows [0, nrows) <- g + rowmap(row) * ld_bytes + colmap(chunk): colmap gives the global byte offset of the image's
+    // 16-byte chunk `chunk` (identity * 16 for a contiguous row); nrows % (4 RPI) == 0
+    template <class RowMap, class ColMap>
+    static __device__ __forceinline__ void dma_in(const char* __restrict__ g, long long ld_bytes, char* lds, int nrows,
+                                                  RowMap rowmap, ColMap colmap, int wave, int lane) {
+        for (int inst = wave; inst < nrows / RPI; inst += 4) {
+            const int row = inst * RPI + lane / CH;
+            const int chunk = (lane ^ row) & (CH - 1);
+            const char* src = g + (long long)rowmap(row) * ld_bytes + colmap(chunk);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + inst * 1024), 16, 0, 0);
+        }
+    }
+    template <class RowMap, class ColMap>
+    static __device__ __forceinline__ void copy_out(char* __restrict__ g, long long ld_bytes, const char* lds, int nrows,
+                                                    RowMap rowmap, ColMap colmap, int wave, int lane) {
+        for (int inst = wave; inst < nrows / RPI; inst += 4) {
+            const int row = inst * RPI + lane / CH;
+            const int chunk = (lane ^ row) & (CH - 1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(lds + inst * 1024 + lane * 16);
+            *reinterpret_cast<f32x4*>(g + (long long)rowmap(row) * ld_bytes + colmap(chunk)) = v;
+        }
+    }
+    template <class RowMap>
+    static __device__ __forceinline__ void dma_in(const char* __restrict__ g, long long ld_bytes, char* lds, int nrows,
+                                                  RowMap rowmap, int wave, int lane) {
+        dma_in(g, ld_bytes, lds, nrows, rowmap, [](int c) { return c * 16; }, wave, lane);
+    }
+    template <class RowMap>
+    static __device__ __forceinline__ void copy_out(char* __restrict__ g, long long ld_bytes, const char* lds, int nrows,
+                                                    RowMap rowmap, int wave, int lane) {
+        copy_out(g, ld_bytes, lds, nrows, rowmap, [](int c) { return c * 16; }, wave, lane);
+    }
+};
+
+// Workgroups of one launch that share an XCD (blockIdx % 8) and its L2 take a compact patch of the tile grid:
+// (n_mt / 4) row tiles x (n_pt / 2) weight tiles per direction, instead of one weight tile and every row tile.
+__device__ __forceinline__ void patch_of_block(int bid, int nblocks, int n_mt, int n_pt, int& d, int& pt, int& mt)
+{
+    const int per_dir = n_mt * n_pt;
+    if ((n_mt & 3) == 0 && (n_pt & 1) == 0 && (nblocks & 7) == 0) {
+        const int x = bid & 7, i = bid >> 3;
+        const int A = n_mt >> 2, Bp = n_pt >> 1;
+        d = i / (A * Bp);
+        const int r = i % (A * Bp);
+        pt = (x & 1) * Bp + r % Bp;
+        mt = (x >> 1) * A + r / Bp;
+    } else {
+        d = bid / per_dir;
+        const int rem = bid % per_dir;
+        pt = rem % n_pt;
+        mt = rem / n_pt;
+    }
+}
+
 // Tile order: blocks that run together on one XCD (blockIdx % 8) take consecutive tiles of a 4 (Q) x 8 (P) patch,
 // so the 32 CUs of an XCD share 4 activation tiles and 8 weight tiles in their L2 at any time.
 // n_p, n_q: tile counts; returns false for the blocks beyond the grid (none when the grid is exact).

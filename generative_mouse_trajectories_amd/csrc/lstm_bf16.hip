@@ -22,6 +22,10 @@ namespace {
 
 using namespace gmt_bf16;
 
+// LDS of the forward step: the mainloop's two stages (128 KiB), reused by the epilogue for half a tile at a time
+// (128 rows): pre-activations / gates [128][512 B], cell state [128][256 B], h [128][128 B] = 112 KiB.
+constexpr int FWD_G_OFF = 0, FWD_C_OFF = 128 * 512, FWD_H_OFF = FWD_C_OFF + 128 * 256;
+
 template <bool RAGGED>
 __global__ __launch_bounds__(NTHREADS)
 void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf16* __restrict__ Hall,
@@ -31,79 +35,99 @@ void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int per_dir = n_mt * n_pt;
-    const int d = blockIdx.x / per_dir, rem = blockIdx.x % per_dir;
-    const int pt = rem % n_pt, mt = rem / n_pt;
+    int d, pt, mt;
+    patch_of_block(blockIdx.x, gridDim.x, n_mt, n_pt, d, pt, mt);
     const int t = d == 0 ? step : L - 1 - step;
     const int tprev = d == 0 ? t - 1 : t + 1;
     const bool has_prev = step > 0;
     const long long ldg = (long long)ndir * 4 * H, ldh = (long long)ndir * H;
-    __bf16* Gt = G + (long long)t * B * ldg + (long long)d * 4 * H;
-    float* Ct = Call + (long long)t * B * ldh + (long long)d * H;
-    __bf16* Ht = Hall + (long long)t * B * ldh + (long long)d * H;
-    const float* Cp = Call + (long long)tprev * B * ldh + (long long)d * H;       // dereferenced only if has_prev
-    const __bf16* Hp = Hall + (long long)tprev * B * ldh + (long long)d * H;
+    // this tile's corner in the [B][..] planes of timestep t (and of the forward pass's predecessor)
+    char* Gt = (char*)(G + ((long long)t * B + (long long)mt * TQ) * ldg + (long long)d * 4 * H + pt * TP);
+    char* Ct = (char*)(Call + ((long long)t * B + (long long)mt * TQ) * ldh + (long long)d * H + pt * (TP / 4));
+    char* Ht = (char*)(Hall + ((long long)t * B + (long long)mt * TQ) * ldh + (long long)d * H + pt * (TP / 4));
+    const char* Cp = (const char*)(Call + ((long long)tprev * B + (long long)mt * TQ) * ldh + (long long)d * H + pt * (TP / 4));
+    const __bf16* Hp = Hall + ((long long)tprev * B + (long long)mt * TQ) * ldh + (long long)d * H;   // full-width rows
 
     f32x16 acc[4][4];
     zero_acc<4, 4>(acc);
-    mainloop<4, 4>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H, Hp + (long long)mt * TQ * ldh, ldh,
-                   has_prev ? H / BK : 0, lds, acc, wave, lane);
+    mainloop<4, 4>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H, Hp, ldh, has_prev ? H / BK : 0, lds, acc, wave, lane);
 
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
-    const int slab = pt * 2 + wp;                              // 32 hidden units
+    using GI = RowImage<512>;
+    using CI = RowImage<256>;
+    using HI = RowImage<128>;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int b = mt * TQ + wq * 128 + j * 32 + lo;
-        bool valid = true;
-        if (RAGGED) valid = t < lengths[b];
-        __bf16* gp = Gt + (long long)b * ldg + slab * 128 + 4 * hi;
-        const long long so = (long long)b * ldh + slab * 32 + 4 * hi;
+    for (int hf = 0; hf < 2; ++hf) {
+        auto rowmap = [hf](int r) { return (r >> 6) * 128 + hf * 64 + (r & 63); };   // image row -> tile row
+        __syncthreads();                                        // the LDS is free (mainloop / previous half done)
+        GI::dma_in(Gt, ldg * 2, lds + FWD_G_OFF, 128, rowmap, wave, lane);
+        if (has_prev) CI::dma_in(Cp, ldh * 4, lds + FWD_C_OFF, 128, rowmap, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            bf16x4 pre[4];
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * hf + jj;
+            const int rl = wq * 64 + jj * 32 + lo;              // image row of this lane
+            bool valid = true;
+            if (RAGGED) valid = t < lengths[mt * TQ + wq * 128 + j * 32 + lo];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g] = *reinterpret_cast<const bf16x4*>(gp + g * 32 + 8 * g4);
-            f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-            if (has_prev) cp = *reinterpret_cast<const f32x4*>(Cp + so + 8 * g4);
-            float cn[4], hn[4], gi[4], gf[4], gg[4], go[4];
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int ucol = wp * 32 + 8 * g4 + 4 * hi;     // first of this lane's 4 units, within the tile's 64
+                bf16x4 pre[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g4 + e;
-                gi[e] = gmt_sigmoid(acc[0][j][r] + (float)pre[0][e]);
-                gf[e] = gmt_sigmoid(acc[1][j][r] + (float)pre[1][e]);
-                gg[e] = gmt_tanh(acc[2][j][r] + (float)pre[2][e]);
-                go[e] = gmt_sigmoid(acc[3][j][r] + (float)pre[3][e]);
-                cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
-                hn[e] = go[e] * gmt_tanh(cn[e]);
-            }
-            if (RAGGED) {
-                if (!valid) {
-                    bf16x4 hp = pack4(0.f, 0.f, 0.f, 0.f);
-                    if (d == 0 && has_prev) hp = *reinterpret_cast<const bf16x4*>(Hp + so + 8 * g4);
+                for (int g = 0; g < 4; ++g)
+                    pre[g] = *reinterpret_cast<const bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + g * 32 + 8 * g4 + 4 * hi) * 2));
+                f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+                if (has_prev) cp = *reinterpret_cast<const f32x4*>(lds + FWD_C_OFF + CI::addr(rl, ucol * 4));
+                float cn[4], hn[4], gi[4], gf[4], gg[4], go[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        cn[e] = d == 0 ? cp[e] : 0.f;
-                        hn[e] = (float)hp[e];
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    gi[e] = gmt_sigmoid(acc[0][j][r] + (float)pre[0][e]);
+                    gf[e] = gmt_sigmoid(acc[1][j][r] + (float)pre[1][e]);
+                    gg[e] = gmt_tanh(acc[2][j][r] + (float)pre[2][e]);
+                    go[e] = gmt_sigmoid(acc[3][j][r] + (float)pre[3][e]);
+                    cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
+                    hn[e] = go[e] * gmt_tanh(cn[e]);
+                }
+                if (RAGGED) {
+                    if (!valid) {                               // frozen (direction 0) / not started (direction 1)
+                        bf16x4 hp = pack4(0.f, 0.f, 0.f, 0.f);
+                        if (d == 0 && has_prev)
+                            hp = *reinterpret_cast<const bf16x4*>(Hp + (long long)(wq * 128 + j * 32 + lo) * ldh + pt * (TP / 4) + ucol);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            cn[e] = d == 0 ? cp[e] : 0.f;
+                            hn[e] = (float)hp[e];
+                        }
                     }
                 }
+                if (!RAGGED || valid) {                         // (the pre-activations of a skipped row-step stay as they are)
+                    *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 0 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(gi[0], gi[1], gi[2], gi[3]);
+                    *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 1 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(gf[0], gf[1], gf[2], gf[3]);
+                    *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 2 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(gg[0], gg[1], gg[2], gg[3]);
+                    *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 3 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(go[0], go[1], go[2], go[3]);
+                }
+                f32x4 cv = {cn[0], cn[1], cn[2], cn[3]};
+                *reinterpret_cast<f32x4*>(lds + FWD_C_OFF + CI::addr(rl, ucol * 4)) = cv;
+                *reinterpret_cast<bf16x4*>(lds + FWD_H_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
             }
-            if (!RAGGED || valid) {
-                *reinterpret_cast<bf16x4*>(gp + 0 * 32 + 8 * g4) = pack4(gi[0], gi[1], gi[2], gi[3]);
-                *reinterpret_cast<bf16x4*>(gp + 1 * 32 + 8 * g4) = pack4(gf[0], gf[1], gf[2], gf[3]);
-                *reinterpret_cast<bf16x4*>(gp + 2 * 32 + 8 * g4) = pack4(gg[0], gg[1], gg[2], gg[3]);
-                *reinterpret_cast<bf16x4*>(gp + 3 * 32 + 8 * g4) = pack4(go[0], go[1], go[2], go[3]);
-            }
-            f32x4 cv = {cn[0], cn[1], cn[2], cn[3]};
-            *reinterpret_cast<f32x4*>(Ct + so + 8 * g4) = cv;
-            *reinterpret_cast<bf16x4*>(Ht + so + 8 * g4) = pack4(hn[0], hn[1], hn[2], hn[3]);
         }
+        __syncthreads();
+        GI::copy_out(Gt, ldg * 2, lds + FWD_G_OFF, 128, rowmap, wave, lane);
+        CI::copy_out(Ct, ldh * 4, lds + FWD_C_OFF, 128, rowmap, wave, lane);
+        HI::copy_out(Ht, ldh * 2, lds + FWD_H_OFF, 128, rowmap, wave, lane);
     }
 }
 
 // Backward step: 128 (units) x 128 (rows) tiles (K = 4H is long and the output narrow, so the smaller tile is what fills
-// the chip: 2 ndir H/128 B/128 workgroups, two per CU).
+// the chip: ndir H/128 B/128 workgroups, two per CU).  The epilogue handles one accumulator block of every wave at a time
+// (a "quarter": 64 rows x 2 slabs), with the saved gates - overwritten by d(pre-activation) - and the two cell-state
+// planes moving through LDS as whole rows; the carried dc (and the thin dh inputs) are read and written directly.
+constexpr int BWD_G_OFF = 0, BWD_C_OFF = 64 * 512, BWD_CP_OFF = BWD_C_OFF + 64 * 256;      // 32 + 16 + 16 KiB
+
 template <bool RAGGED>
-__global__ __launch_bounds__(NTHREADS)
+__global__ __launch_bounds__(NTHREADS, 2)
 void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call, const __bf16* __restrict__ dHout,
                           const float* __restrict__ dh_fin, float* __restrict__ dc_carry, float* __restrict__ dh_carry,
                           const __bf16* __restrict__ WhhT, const int* __restrict__ lengths,
@@ -113,43 +137,56 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
     using T = Tile<2, 2>;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int per_dir = n_mt * n_pt;
-    const int d = blockIdx.x / per_dir, rem = blockIdx.x % per_dir;
-    const int pt = rem % n_pt, mt = rem / n_pt;
+    int d, pt, mt;
+    patch_of_block(blockIdx.x, gridDim.x, n_mt, n_pt, d, pt, mt);
     const int t = d == 0 ? L - 1 - step : step;
     const int tnext = d == 0 ? t + 1 : t - 1;                  // processed by the previous launch of this sweep
     const int tprev = d == 0 ? t - 1 : t + 1;                  // the forward pass's predecessor of t
     const bool has_next = step > 0, has_prev = step < L - 1;
     const long long ldg = (long long)ndir * 4 * H, ldh = (long long)ndir * H;
-    __bf16* Gt = G + (long long)t * B * ldg + (long long)d * 4 * H;
-    const __bf16* Gn = G + (long long)tnext * B * ldg + (long long)d * 4 * H;
-    const float* Ct = Call + (long long)t * B * ldh + (long long)d * H;
-    const float* Cp = Call + (long long)tprev * B * ldh + (long long)d * H;
-    const __bf16* dHt = dHout ? dHout + (long long)t * B * ldh + (long long)d * H : nullptr;
-    float* dcc = dc_carry + (long long)d * B * H;
-    float* dhc = dh_carry + (long long)d * B * H;
-    const float* dhf = dh_fin + (long long)d * B * H;
+    const long long row0 = (long long)mt * T::TQ;
+    // tile corners: rows row0.., units 128 pt.. (4 slabs = 512 gate columns) of direction d
+    char* Gt = (char*)(G + ((long long)t * B + row0) * ldg + (long long)d * 4 * H + pt * 512);
+    const __bf16* Gn = G + ((long long)tnext * B + row0) * ldg + (long long)d * 4 * H;
+    const char* Ct = (const char*)(Call + ((long long)t * B + row0) * ldh + (long long)d * H + pt * 128);
+    const char* Cp = (const char*)(Call + ((long long)tprev * B + row0) * ldh + (long long)d * H + pt * 128);
+    const __bf16* dHt = dHout ? dHout + ((long long)t * B + row0) * ldh + (long long)d * H + pt * 128 : nullptr;
+    float* dcc = dc_carry + ((long long)d * B + row0) * H + pt * 128;
+    float* dhc = dh_carry + ((long long)d * B + row0) * H + pt * 128;
+    const float* dhf = dh_fin + ((long long)d * B + row0) * H + pt * 128;
 
     f32x16 acc[2][2];
     zero_acc<2, 2>(acc);
-    mainloop<2, 2>(WhhT + ((long long)d * H + (long long)pt * T::TP) * 4 * H, 4LL * H, Gn + (long long)mt * T::TQ * ldg, ldg,
-                   has_next ? 4 * H / BK : 0, lds, acc, wave, lane);
+    mainloop<2, 2>(WhhT + ((long long)d * H + (long long)pt * T::TP) * 4 * H, 4LL * H, Gn, ldg, has_next ? 4 * H / BK : 0,
+                   lds, acc, wave, lane);
 
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
+    using GI = RowImage<512>;
+    using CI = RowImage<256>;
+    const int rl = wq * 32 + lo;                               // image row of this lane in every quarter
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int b = mt * T::TQ + wq * 64 + j * 32 + lo;
+        auto rowmap = [j](int r) { return (r >> 5) * 64 + j * 32 + (r & 31); };
+        const int brow = wq * 64 + j * 32 + lo;                // this lane's row within the tile
         bool valid = true;
-        if (RAGGED) valid = t < lengths[b];
+        if (RAGGED) valid = t < lengths[row0 + brow];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int slab = pt * 4 + wp * 2 + i;
-            __bf16* gp = Gt + (long long)b * ldg + slab * 128 + 4 * hi;
+            // image columns: [wave-row 0: slab i][wave-row 1: slab 2 + i]
+            auto gcol = [i](int c) { return (((c >> 4) * 2 + i) * 128) * 2 + (c & 15) * 16; };
+            auto ccol = [i](int c) { return (((c >> 3) * 2 + i) * 32) * 4 + (c & 7) * 16; };
+            __syncthreads();
+            GI::dma_in(Gt, ldg * 2, lds + BWD_G_OFF, 64, rowmap, gcol, wave, lane);
+            CI::dma_in(Ct, ldh * 4, lds + BWD_C_OFF, 64, rowmap, ccol, wave, lane);
+            if (has_prev) CI::dma_in(Cp, ldh * 4, lds + BWD_CP_OFF, 64, rowmap, ccol, wave, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int slab_u = (wp * 2 + i) * 32;              // first unit of this wave's slab, within the tile's 128
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int u = slab * 32 + 8 * g4 + 4 * hi;     // first of 4 consecutive units
-                const long long so = (long long)b * ldh + u;
-                const long long co = (long long)b * H + u;
+                const int u = slab_u + 8 * g4 + 4 * hi;
+                const long long so = (long long)brow * ldh + u;
+                const long long co = (long long)brow * H + u;
                 float dh[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dh[e] = acc[i][j][4 * g4 + e];
@@ -165,6 +202,7 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
                 }
                 f32x4 dc = {0.f, 0.f, 0.f, 0.f};
                 if (has_next) dc = *reinterpret_cast<const f32x4*>(dcc + co);
+                const int gbyte = wp * 256 + (8 * g4 + 4 * hi) * 2;           // + gate * 64
                 if (RAGGED) {
                     if (d == 0 && has_next) {
                         const f32x4 v = *reinterpret_cast<const f32x4*>(dhc + co);
@@ -175,7 +213,7 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
                         // frozen (direction 0) or not yet started (direction 1): no cell here; direction 0 passes dh and dc on
                         const bf16x4 z = pack4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) *reinterpret_cast<bf16x4*>(gp + g * 32 + 8 * g4) = z;
+                        for (int g = 0; g < 4; ++g) *reinterpret_cast<bf16x4*>(lds + BWD_G_OFF + GI::addr(rl, gbyte + g * 64)) = z;
                         f32x4 dv = {dh[0], dh[1], dh[2], dh[3]};
                         if (d == 0) *reinterpret_cast<f32x4*>(dhc + co) = dv;
                         if (!has_next) *reinterpret_cast<f32x4*>(dcc + co) = dc;
@@ -184,10 +222,11 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
                 }
                 bf16x4 gt[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gt[g] = *reinterpret_cast<const bf16x4*>(gp + g * 32 + 8 * g4);
-                const f32x4 c = *reinterpret_cast<const f32x4*>(Ct + so);
+                for (int g = 0; g < 4; ++g) gt[g] = *reinterpret_cast<const bf16x4*>(lds + BWD_G_OFF + GI::addr(rl, gbyte + g * 64));
+                const int cbyte = wp * 128 + (8 * g4 + 4 * hi) * 4;
+                const f32x4 c = *reinterpret_cast<const f32x4*>(lds + BWD_C_OFF + CI::addr(rl, cbyte));
                 f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-                if (has_prev) cp = *reinterpret_cast<const f32x4*>(Cp + so);
+                if (has_prev) cp = *reinterpret_cast<const f32x4*>(lds + BWD_CP_OFF + CI::addr(rl, cbyte));
                 float da[4][4];
                 f32x4 dcn;
 #pragma unroll
@@ -203,13 +242,15 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<bf16x4*>(gp + g * 32 + 8 * g4) = pack4(da[g][0], da[g][1], da[g][2], da[g][3]);
+                    *reinterpret_cast<bf16x4*>(lds + BWD_G_OFF + GI::addr(rl, gbyte + g * 64)) = pack4(da[g][0], da[g][1], da[g][2], da[g][3]);
                 *reinterpret_cast<f32x4*>(dcc + co) = dcn;
                 if (RAGGED && d == 0) {
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(dhc + co) = z;
                 }
             }
+            __syncthreads();
+            GI::copy_out(Gt, ldg * 2, lds + BWD_G_OFF, 64, rowmap, gcol, wave, lane);
         }
     }
 }
