@@ -39,15 +39,15 @@ constexpr int TP = Tile<4, 4>::TP, TQ = Tile<4, 4>::TQ, LDS_BYTES = Tile<4, 4>::
 
 // ROWS x 64 k of a row-major bf16 operand -> LDS image at lds_tile.  g points at (tile row 0, k0); every row and
 // k-range must exist (callers check M % tile == 0, N % tile == 0, K % 64 == 0).
-template <int ROWS>
+template <int ROWS, int NWAVES = 4>
 __device__ __forceinline__ void stage(const __bf16* __restrict__ g, long long ld, char* lds_tile, int wave, int lane)
 {
 #pragma unroll
-    for (int j = 0; j < ROWS / 32; ++j) {
-        const int row = j * 32 + wave * 8 + (lane >> 3);
+    for (int j = 0; j < ROWS / (8 * NWAVES); ++j) {
+        const int row = j * 8 * NWAVES + wave * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         const __bf16* src = g + (long long)row * ld + chunk * 8;
-        char* dst = lds_tile + (j * 32 + wave * 8) * 128;             // wave-uniform; the DMA adds lane * 16
+        char* dst = lds_tile + (j * 8 * NWAVES + wave * 8) * 128;     // wave-uniform; the DMA adds lane * 16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
@@ -55,17 +55,19 @@ __device__ __forceinline__ void stage(const __bf16* __restrict__ g, long long ld
 
 // acc[i][j] += P-block i (32 rows) x Q-block j (32 rows) of this wave over nk K-tiles.
 // lds: Tile::LDS_BYTES, 16-byte aligned.  No barrier after the last tile: callers that reuse the LDS put one.
-template <int NPB, int NQB>
+// NWQ waves along Q (2 or 4; always 2 along P): the workgroup tile is (64 NPB) x (32 NQB NWQ), 128 NWQ threads.
+template <int NPB, int NQB, int NWQ = 2>
 __device__ __forceinline__ void mainloop(const __bf16* __restrict__ Pg, long long ldp, const __bf16* __restrict__ Qg,
                                          long long ldq, int nk, char* lds, f32x16 (&acc)[NPB][NQB], int wave, int lane)
 {
-    using T = Tile<NPB, NQB>;
-    const int wp = wave >> 1, wq = wave & 1;
+    using T = Tile<NPB, NQB * NWQ / 2>;
+    constexpr int NWV = 2 * NWQ;
+    const int wp = wave / NWQ, wq = wave % NWQ;
     const int lo = lane & 31, hi = lane >> 5;
     const int swz = (lo >> 1) & 7;
     if (nk > 0) {
-        stage<T::TP>(Pg, ldp, lds, wave, lane);
-        stage<T::TQ>(Qg, ldq, lds + T::TP * 128, wave, lane);
+        stage<T::TP, NWV>(Pg, ldp, lds, wave, lane);
+        stage<T::TQ, NWV>(Qg, ldq, lds + T::TP * 128, wave, lane);
     }
     for (int t = 0; t < nk; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -73,24 +75,102 @@ __device__ __forceinline__ void mainloop(const __bf16* __restrict__ Pg, long lon
         char* cur = lds + (t & 1) * T::STAGE_BYTES;
         if (t + 1 < nk) {
             char* nxt = lds + ((t + 1) & 1) * T::STAGE_BYTES;
-            stage<T::TP>(Pg + (long long)(t + 1) * BK, ldp, nxt, wave, lane);
-            stage<T::TQ>(Qg + (long long)(t + 1) * BK, ldq, nxt + T::TP * 128, wave, lane);
+            stage<T::TP, NWV>(Pg + (long long)(t + 1) * BK, ldp, nxt, wave, lane);
+            stage<T::TQ, NWV>(Qg + (long long)(t + 1) * BK, ldq, nxt + T::TP * 128, wave, lane);
         }
         const char* pt = cur + (wp * (T::TP / 2) + lo) * 128;
-        const char* qt = cur + T::TP * 128 + (wq * (T::TQ / 2) + lo) * 128;
+        const char* qt = cur + T::TP * 128 + (wq * (32 * NQB) + lo) * 128;
+        // fragments of k-step s+1 are requested before the MFMAs of k-step s (two register sets): with one or two waves per
+        // SIMD nothing else hides the LDS latency, and the compiler on its own reads, waits, computes, reads, ...
+        bf16x8 pf[2][NPB], qf[2][NQB];
+        auto read_frags = [&](int s, int set) {
+            const int off = ((2 * s + hi) ^ swz) << 4;
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) pf[set][i] = *reinterpret_cast<const bf16x8*>(pt + i * 32 * 128 + off);
+#pragma unroll
+            for (int j = 0; j < NQB; ++j) qf[set][j] = *reinterpret_cast<const bf16x8*>(qt + j * 32 * 128 + off);
+        };
+        read_frags(0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            if (s < 3) read_frags(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+#pragma unroll
+                for (int j = 0; j < NQB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[s & 1][i], qf[s & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// The same contraction with a deeper pipeline: K-tiles of 32 in a ring of four LDS buffers (same 128 KiB for the 256 x 256
+// tile), three tiles in flight.  With two buffers a tile's loads are issued one tile of MFMA work (~2 000 cycles) before
+// they are needed, less than the load latency under load, and every K-tile then waits for them (measured: ~5 000 cycles per
+// 64 k); here a tile has three tiles' worth of time.  The barrier is the raw s_barrier with a COUNTED vmcnt - __syncthreads()
+// would drain the LDS-DMA queue (cdna_hip_programming.md, "Pipelining across barriers").
+// LDS image of a stage: [row][4 chunks of 16 B], chunk c of row r at position c ^ ((r >> 2) & 3): the 16 lanes of a
+// ds_read_b128 group then cover the 16 slots of a 256-byte bank row exactly once.
+constexpr int RBK = 32;
+template <int ROWS, int NWAVES>
+__device__ __forceinline__ void stage32(const __bf16* __restrict__ g, long long ld, char* lds_tile, int wave, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < ROWS / (16 * NWAVES); ++j) {
+        const int row = j * 16 * NWAVES + wave * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        const __bf16* src = g + (long long)row * ld + chunk * 8;
+        char* dst = lds_tile + (j * 16 * NWAVES + wave * 16) * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+template <int NPB, int NQB, int NWQ>
+__device__ __forceinline__ void mainloop_ring(const __bf16* __restrict__ Pg, long long ldp, const __bf16* __restrict__ Qg,
+                                              long long ldq, int nk32, char* lds, f32x16 (&acc)[NPB][NQB], int wave, int lane)
+{
+    constexpr int TPr = 64 * NPB, TQr = 32 * NQB * NWQ, NWV = 2 * NWQ;
+    constexpr int STG = (TPr + TQr) * RBK * 2;                  // bytes per ring slot
+    constexpr int LPT = (TPr + TQr) / (16 * NWV);               // DMA instructions per thread and tile
+    const int wp = wave / NWQ, wq = wave % NWQ;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int swz = (lo >> 2) & 3;
+    auto issue = [&](int t) {
+        char* b = lds + (t & 3) * STG;
+        stage32<TPr, NWV>(Pg + (long long)t * RBK, ldp, b, wave, lane);
+        stage32<TQr, NWV>(Qg + (long long)t * RBK, ldq, b + TPr * 64, wave, lane);
+    };
+    for (int t = 0; t < 3 && t < nk32; ++t) issue(t);
+    for (int t = 0; t < nk32; ++t) {
+        // tile t must have landed: at most the tiles t+1, t+2 (if they exist) may still be in flight
+        const int ahead = nk32 - 1 - t;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // ... for every wave; and everybody is done with tile t-1
+        if (t + 3 < nk32) issue(t + 3);                         // into the slot tile t-1 used
+        const char* cur = lds + (t & 3) * STG;
+        const char* pt = cur + (wp * (TPr / 2) + lo) * 64;
+        const char* qt = cur + TPr * 64 + (wq * (32 * NQB) + lo) * 64;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
             const int off = ((2 * s + hi) ^ swz) << 4;
             bf16x8 pf[NPB], qf[NQB];
 #pragma unroll
-            for (int i = 0; i < NPB; ++i) pf[i] = *reinterpret_cast<const bf16x8*>(pt + i * 32 * 128 + off);
+            for (int i = 0; i < NPB; ++i) pf[i] = *reinterpret_cast<const bf16x8*>(pt + i * 32 * 64 + off);
 #pragma unroll
-            for (int j = 0; j < NQB; ++j) qf[j] = *reinterpret_cast<const bf16x8*>(qt + j * 32 * 128 + off);
+            for (int j = 0; j < NQB; ++j) qf[j] = *reinterpret_cast<const bf16x8*>(qt + j * 32 * 64 + off);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < NPB; ++i)
 #pragma unroll
                 for (int j = 0; j < NQB; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
 }

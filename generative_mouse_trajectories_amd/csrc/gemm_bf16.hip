@@ -13,9 +13,12 @@ using namespace gmt_bf16;
 constexpr int C_PITCH = TP * 2 + 16;                           // bytes per row of the staged output tile
 constexpr int GEMM_LDS = TQ * C_PITCH > LDS_BYTES ? TQ * C_PITCH : LDS_BYTES;
 
-// EPI: 0 = +bias (or nothing), 1 = lrelu(+bias), 2 = * lrelu'(act)
+// EPI: 0 = +bias (or nothing), 1 = lrelu(+bias), 2 = * lrelu'(act).  8 waves (2 along the weights x 4 along the rows, two per
+// SIMD so that one computes while the other waits at the K-tile barrier), each 128 x 64 of the 256 x 256 tile.
+constexpr int GEMM_THREADS = 512;
+
 template <int EPI>
-__global__ __launch_bounds__(NTHREADS)
+__global__ __launch_bounds__(GEMM_THREADS)
 void gemm_nt_kernel(const __bf16* __restrict__ A, long long lda, const __bf16* __restrict__ W, long long ldw,
                     __bf16* __restrict__ C, long long ldc, const float* __restrict__ bias,
                     const __bf16* __restrict__ act, long long ldact, float slope, int n_p, long long n_q, int nk)
@@ -25,13 +28,13 @@ void gemm_nt_kernel(const __bf16* __restrict__ A, long long lda, const __bf16* _
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tp; long long tq;
     tile_of_block(blockIdx.x, gridDim.x, n_p, n_q, tp, tq);
-    f32x16 acc[4][4];
-    zero_acc(acc);
-    mainloop<4, 4>(W + (long long)tp * TP * ldw, ldw, A + tq * TQ * lda, lda, nk, lds, acc, wave, lane);
+    f32x16 acc[4][2];
+    zero_acc<4, 2>(acc);
+    mainloop<4, 2, 4>(W + (long long)tp * TP * ldw, ldw, A + tq * TQ * lda, lda, nk, lds, acc, wave, lane);
 
     // Epilogue through LDS: a lane's natural store is 8 bytes of one row (16 with its hi partner) - a tile would leave as
     // 8 192 partial-line requests.  The tile is written to LDS as C[m][n] (pitch 528 B) and leaves as full 512-byte rows.
-    const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
+    const int wp = wave >> 2, wq = wave & 3, lo = lane & 31, hi = lane >> 5;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -41,8 +44,8 @@ void gemm_nt_kernel(const __bf16* __restrict__ A, long long lda, const __bf16* _
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if (bias) bv = *reinterpret_cast<const f32x4*>(bias + tp * TP + nl);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ml = wq * 128 + j * 32 + lo;
+            for (int j = 0; j < 2; ++j) {
+                const int ml = wq * 64 + j * 32 + lo;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
@@ -59,8 +62,8 @@ void gemm_nt_kernel(const __bf16* __restrict__ A, long long lda, const __bf16* _
     const long long m0 = tq * TQ;
     const int n0 = tp * TP + (tid & 31) * 8;
 #pragma unroll 4
-    for (int it = 0; it < TQ / 8; ++it) {
-        const int row = it * 8 + (tid >> 5);
+    for (int it = 0; it < TQ / 16; ++it) {
+        const int row = it * 16 + (tid >> 5);
         bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + row * C_PITCH + (tid & 31) * 16);
         if (EPI == 2) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(act + (m0 + row) * ldact + n0);
@@ -82,7 +85,7 @@ int launch_nt(const __bf16* A, long long lda, const __bf16* W, long long ldw, __
     const long long n_q = M / TQ;
     const long long nblocks = n_p * n_q;
     if (nblocks > 0x7fffffffLL) return GMT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NTHREADS), GEMM_LDS, stream, A, lda, W, ldw, C, ldc, bias, act, ldact,
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(GEMM_THREADS), GEMM_LDS, stream, A, lda, W, ldw, C, ldc, bias, act, ldact,
                        slope, n_p, n_q, K / BK);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
