@@ -10,7 +10,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libgmt_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 ERRORS = {-1: 'bad argument (null pointer / shape / alignment)', -2: 'unsupported configuration',
@@ -66,8 +66,8 @@ _SIGS = {
     'gmt_wgrad_noalloc': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_f, ctypes.c_uint, c_p],
     'gmt_encoder_fwd': [c_p] * 9 + [c_i, c_i, c_i, c_f, c_f, c_p],
     'gmt_bf16_gemm_nt': [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_p, c_ll, c_i, c_f, c_ll, c_i, c_i, c_p],
-    'gmt_bf16_lstm_layer_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
-    'gmt_bf16_lstm_layer_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    'gmt_bf16_lstm_layer_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.c_uint, c_p],
+    'gmt_bf16_lstm_layer_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.c_uint, c_p],
     'gmt_bf16_wgrad_tn': [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, c_p],
     'gmt_dx_gemm_resident': [c_i, c_i],
     'gmt_dx_gemm': [c_p, c_p, c_p, c_p, c_f, c_ll, c_i, c_i, c_i, c_p],

@@ -107,74 +107,6 @@ __device__ __forceinline__ void mainloop(const __bf16* __restrict__ Pg, long lon
     }
 }
 
-// The same contraction with a deeper pipeline: K-tiles of 32 in a ring of four LDS buffers (same 128 KiB for the 256 x 256
-// tile), three tiles in flight.  With two buffers a tile's loads are issued one tile of MFMA work (~2 000 cycles) before
-// they are needed, less than the load latency under load, and every K-tile then waits for them (measured: ~5 000 cycles per
-// 64 k); here a tile has three tiles' worth of time.  The barrier is the raw s_barrier with a COUNTED vmcnt - __syncthreads()
-// would drain the LDS-DMA queue (cdna_hip_programming.md, "Pipelining across barriers").
-// LDS image of a stage: [row][4 chunks of 16 B], chunk c of row r at position c ^ ((r >> 2) & 3): the 16 lanes of a
-// ds_read_b128 group then cover the 16 slots of a 256-byte bank row exactly once.
-constexpr int RBK = 32;
-template <int ROWS, int NWAVES>
-__device__ __forceinline__ void stage32(const __bf16* __restrict__ g, long long ld, char* lds_tile, int wave, int lane)
-{
-#pragma unroll
-    for (int j = 0; j < ROWS / (16 * NWAVES); ++j) {
-        const int row = j * 16 * NWAVES + wave * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        const __bf16* src = g + (long long)row * ld + chunk * 8;
-        char* dst = lds_tile + (j * 16 * NWAVES + wave * 16) * 64;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-}
-
-template <int NPB, int NQB, int NWQ>
-__device__ __forceinline__ void mainloop_ring(const __bf16* __restrict__ Pg, long long ldp, const __bf16* __restrict__ Qg,
-                                              long long ldq, int nk32, char* lds, f32x16 (&acc)[NPB][NQB], int wave, int lane)
-{
-    constexpr int TPr = 64 * NPB, TQr = 32 * NQB * NWQ, NWV = 2 * NWQ;
-    constexpr int STG = (TPr + TQr) * RBK * 2;                  // bytes per ring slot
-    constexpr int LPT = (TPr + TQr) / (16 * NWV);               // DMA instructions per thread and tile
-    const int wp = wave / NWQ, wq = wave % NWQ;
-    const int lo = lane & 31, hi = lane >> 5;
-    const int swz = (lo >> 2) & 3;
-    auto issue = [&](int t) {
-        char* b = lds + (t & 3) * STG;
-        stage32<TPr, NWV>(Pg + (long long)t * RBK, ldp, b, wave, lane);
-        stage32<TQr, NWV>(Qg + (long long)t * RBK, ldq, b + TPr * 64, wave, lane);
-    };
-    for (int t = 0; t < 3 && t < nk32; ++t) issue(t);
-    for (int t = 0; t < nk32; ++t) {
-        // tile t must have landed: at most the tiles t+1, t+2 (if they exist) may still be in flight
-        const int ahead = nk32 - 1 - t;
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // ... for every wave; and everybody is done with tile t-1
-        if (t + 3 < nk32) issue(t + 3);                         // into the slot tile t-1 used
-        const char* cur = lds + (t & 3) * STG;
-        const char* pt = cur + (wp * (TPr / 2) + lo) * 64;
-        const char* qt = cur + TPr * 64 + (wq * (32 * NQB) + lo) * 64;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int off = ((2 * s + hi) ^ swz) << 4;
-            bf16x8 pf[NPB], qf[NQB];
-#pragma unroll
-            for (int i = 0; i < NPB; ++i) pf[i] = *reinterpret_cast<const bf16x8*>(pt + i * 32 * 64 + off);
-#pragma unroll
-            for (int j = 0; j < NQB; ++j) qf[j] = *reinterpret_cast<const bf16x8*>(qt + j * 32 * 64 + off);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < NPB; ++i)
-#pragma unroll
-                for (int j = 0; j < NQB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
-    }
-}
-
 template <int NPB, int NQB>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NPB][NQB])
 {

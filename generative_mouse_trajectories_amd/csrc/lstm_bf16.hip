@@ -17,6 +17,7 @@
 // last valid h, so h_all[L-1] is the final state), direction 1 holds zero state until t = len-1 (final state =
 // h_all[0]); the backward sweep writes dA = 0 for those row-steps.
 #include "bf16_tile.h"
+#include "lstm_tile.h"      // the counter-based dropout mask shared with the fp32 kernels (gmt_keep_pair_hash)
 
 namespace {
 
@@ -24,13 +25,24 @@ using namespace gmt_bf16;
 
 // LDS of the forward step: the mainloop's two stages (128 KiB), reused by the epilogue for half a tile at a time
 // (128 rows): pre-activations / gates [128][512 B], cell state [128][256 B], h [128][128 B] = 112 KiB.
-constexpr int FWD_G_OFF = 0, FWD_C_OFF = 128 * 512, FWD_H_OFF = FWD_C_OFF + 128 * 256;
+constexpr int FWD_G_OFF = 0, FWD_C_OFF = 128 * 512, FWD_H_OFF = FWD_C_OFF + 128 * 256, FWD_HD_OFF = FWD_H_OFF + 128 * 128;
+
+// keep-and-scale of 4 consecutive elements starting at idx (idx % 4 == 0) of the inter-layer dropout mask (RG.py:725): the
+// same function of (seed, element index in [L][B][ndir*H]) as the fp32 path's gmt_keep16, so ops.dropout_keep_mask replays it
+__device__ __forceinline__ void drop4(float (&v)[4], uint32_t idx, uint32_t seed, uint32_t thresh16, float scale)
+{
+    const uint32_t h0 = gmt_keep_pair_hash(idx >> 1, seed), h1 = gmt_keep_pair_hash((idx >> 1) + 1u, seed);
+    v[0] = (h0 & 0xffffu) >= thresh16 ? v[0] * scale : 0.f;
+    v[1] = (h0 >> 16) >= thresh16 ? v[1] * scale : 0.f;
+    v[2] = (h1 & 0xffffu) >= thresh16 ? v[2] * scale : 0.f;
+    v[3] = (h1 >> 16) >= thresh16 ? v[3] * scale : 0.f;
+}
 
 template <bool RAGGED>
 __global__ __launch_bounds__(NTHREADS)
 void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf16* __restrict__ Hall,
-                          const __bf16* __restrict__ Whh, const int* __restrict__ lengths,
-                          int L, int B, int H, int ndir, int step, int n_mt, int n_pt)
+                          __bf16* __restrict__ Hdrop, const __bf16* __restrict__ Whh, const int* __restrict__ lengths,
+                          int L, int B, int H, int ndir, int step, int n_mt, int n_pt, float drop_p, uint32_t drop_seed)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -45,6 +57,9 @@ void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf
     char* Gt = (char*)(G + ((long long)t * B + (long long)mt * TQ) * ldg + (long long)d * 4 * H + pt * TP);
     char* Ct = (char*)(Call + ((long long)t * B + (long long)mt * TQ) * ldh + (long long)d * H + pt * (TP / 4));
     char* Ht = (char*)(Hall + ((long long)t * B + (long long)mt * TQ) * ldh + (long long)d * H + pt * (TP / 4));
+    char* Hdt = Hdrop ? (char*)(Hdrop + ((long long)t * B + (long long)mt * TQ) * ldh + (long long)d * H + pt * (TP / 4)) : nullptr;
+    const uint32_t thresh16 = (uint32_t)(drop_p * 65536.0f);
+    const float keep_scale = 1.0f / (1.0f - drop_p);
     const char* Cp = (const char*)(Call + ((long long)tprev * B + (long long)mt * TQ) * ldh + (long long)d * H + pt * (TP / 4));
     const __bf16* Hp = Hall + ((long long)tprev * B + (long long)mt * TQ) * ldh + (long long)d * H;   // full-width rows
 
@@ -111,12 +126,18 @@ void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf
                 f32x4 cv = {cn[0], cn[1], cn[2], cn[3]};
                 *reinterpret_cast<f32x4*>(lds + FWD_C_OFF + CI::addr(rl, ucol * 4)) = cv;
                 *reinterpret_cast<bf16x4*>(lds + FWD_H_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
+                if (Hdt) {                                      // the next layer's input: h after the inter-layer dropout
+                    const long long row = (long long)t * B + mt * TQ + wq * 128 + j * 32 + lo;
+                    drop4(hn, (uint32_t)(row * ldh + d * H + pt * (TP / 4) + ucol), drop_seed, thresh16, keep_scale);
+                    *reinterpret_cast<bf16x4*>(lds + FWD_HD_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
+                }
             }
         }
         __syncthreads();
         GI::copy_out(Gt, ldg * 2, lds + FWD_G_OFF, 128, rowmap, wave, lane);
         CI::copy_out(Ct, ldh * 4, lds + FWD_C_OFF, 128, rowmap, wave, lane);
         HI::copy_out(Ht, ldh * 2, lds + FWD_H_OFF, 128, rowmap, wave, lane);
+        if (Hdt) HI::copy_out(Hdt, ldh * 2, lds + FWD_HD_OFF, 128, rowmap, wave, lane);
     }
 }
 
@@ -131,10 +152,12 @@ __global__ __launch_bounds__(NTHREADS, 2)
 void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call, const __bf16* __restrict__ dHout,
                           const float* __restrict__ dh_fin, float* __restrict__ dc_carry, float* __restrict__ dh_carry,
                           const __bf16* __restrict__ WhhT, const int* __restrict__ lengths,
-                          int L, int B, int H, int ndir, int step, int n_mt, int n_pt)
+                          int L, int B, int H, int ndir, int step, int n_mt, int n_pt, float drop_p, uint32_t drop_seed)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using T = Tile<2, 2>;
+    const uint32_t thresh16 = (uint32_t)(drop_p * 65536.0f);
+    const float keep_scale = 1.0f / (1.0f - drop_p);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int d, pt, mt;
@@ -192,8 +215,11 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
                 for (int e = 0; e < 4; ++e) dh[e] = acc[i][j][4 * g4 + e];
                 if (dHt) {
                     const bf16x4 v = *reinterpret_cast<const bf16x4*>(dHt + so);
+                    float dv[4] = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+                    // dh_out is the gradient of the DROPPED output (the layer above read h through the mask)
+                    if (thresh16) drop4(dv, (uint32_t)(((long long)t * B + row0 + brow) * ldh + d * H + pt * 128 + u), drop_seed, thresh16, keep_scale);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dh[e] += (float)v[e];
+                    for (int e = 0; e < 4; ++e) dh[e] += dv[e];
                 }
                 if (step == 0) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(dhf + co);
@@ -257,9 +283,12 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
 
 }  // namespace
 
-extern "C" int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, const void* w_hh, const int* lengths,
-                                       int ragged, int L, int B, int H, int ndir, hipStream_t stream)
+extern "C" int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, void* h_drop, const void* w_hh,
+                                       const int* lengths, int ragged, int L, int B, int H, int ndir, float drop_p,
+                                       unsigned int drop_seed, hipStream_t stream)
 {
+    GMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (h_drop == nullptr) == (drop_p == 0.f));
+    GMT_CHECK_ARG((long long)L * B * ndir * H < 0xffffffffLL);       // the mask's element counter is 32 bits
     GMT_CHECK_ARG(gates && c_all && h_all && w_hh && L >= 1 && (ndir == 1 || ndir == 2));
     GMT_CHECK_ARG(B > 0 && B % TQ == 0 && H > 0 && (4 * H) % TP == 0 && H % BK == 0 && (!ragged || lengths));
     const int n_mt = B / TQ, n_pt = 4 * H / TP;
@@ -268,15 +297,17 @@ extern "C" int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, c
         return GMT_ERR_HIP;
     for (int step = 0; step < L; ++step)
         hipLaunchKernelGGL(k, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), LDS_BYTES, stream, (__bf16*)gates, c_all, (__bf16*)h_all,
-                           (const __bf16*)w_hh, lengths, L, B, H, ndir, step, n_mt, n_pt);
+                           (__bf16*)h_drop, (const __bf16*)w_hh, lengths, L, B, H, ndir, step, n_mt, n_pt, drop_p, drop_seed);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }
 
 extern "C" int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const void* dh_out, const float* dh_fin,
                                        float* dc_carry, float* dh_carry, const void* w_hhT, const int* lengths,
-                                       int ragged, int L, int B, int H, int ndir, hipStream_t stream)
+                                       int ragged, int L, int B, int H, int ndir, float drop_p, unsigned int drop_seed,
+                                       hipStream_t stream)
 {
+    GMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || dh_out));
     using T = Tile<2, 2>;
     GMT_CHECK_ARG(gates && c_all && dh_fin && dc_carry && w_hhT && L >= 1 && (ndir == 1 || ndir == 2));
     GMT_CHECK_ARG(B > 0 && B % 256 == 0 && H > 0 && H % T::TP == 0 && (!ragged || (lengths && dh_carry)));
@@ -287,7 +318,7 @@ extern "C" int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const vo
     for (int step = 0; step < L; ++step)
         hipLaunchKernelGGL(k, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), T::LDS_BYTES, stream, (__bf16*)gates, c_all,
                            (const __bf16*)dh_out, dh_fin, dc_carry, dh_carry, (const __bf16*)w_hhT, lengths, L, B, H, ndir, step,
-                           n_mt, n_pt);
+                           n_mt, n_pt, drop_p, drop_seed);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }

@@ -280,13 +280,14 @@ class Discriminator(nn.Module):
         fe = self.feature_encoder
         slope = float(fe[1].negative_slope)
         if self.bf16:
-            # config 3: hoisted bf16 GEMMs + one launch per timestep (ops_bf16); no inter-layer dropout on this path yet
-            if self.training and float(self.config.lstm_dropout) > 0:
-                raise NotImplementedError("compute_dtype bf16 runs with lstm_dropout = 0 (the fused mask is not built for this path)")
+            # config 3: hoisted bf16 GEMMs + one launch per timestep (ops_bf16)
+            p = float(self.config.lstm_dropout) if self.training else 0.0
+            if p > 0 and dropout_seed is None:
+                dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
             w1, w2 = sn_w.pop(0), sn_w.pop(0)
             lw = [w for l in range(self.config.discriminator_num_layers) for w in self.lstm.layer_weights(l)]
             h_final = ops_bf16.critic_body(pos_tm, dts_tm, lengths_i32, slope, 1e-8, self.config.discriminator_num_layers,
-                                           w1, fe[0].bias, w2, fe[2].bias, lw)
+                                           w1, fe[0].bias, w2, fe[2].bias, lw, (p, dropout_seed or 0))
             return self.run_sequential(self.output_layers, h_final, sn_w)
         fused_enc = self.fuse_input_gemm and fe[3].negative_slope == fe[1].negative_slope
         if fused_enc:

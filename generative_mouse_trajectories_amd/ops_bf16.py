@@ -10,8 +10,7 @@ of a CU, so the persistent one-workgroup-per-32-rows kernels of `ops` do not app
 The critic body (kinematics -> feature encoder -> BiLSTM stack -> final hidden states, RG.py:757-778) is ONE autograd
 Function so that the big buffers are reused in place (gates -> d(pre-activation)).
 
-Not covered yet (documented in DESIGN.md section 7): the gradient penalty's double backward and the generator at H = 512;
-the inter-layer dropout of nn.LSTM (this path runs with lstm_dropout = 0)."""
+Not covered yet (documented in DESIGN.md section 7): the gradient penalty's double backward and the generator at H = 512."""
 from __future__ import annotations
 
 from typing import List, Optional
@@ -93,7 +92,7 @@ class CriticBodyBf16Fn(torch.autograd.Function):
     (final hidden state of the last layer, forward | reverse: RG.py:776-778)."""
 
     @staticmethod
-    def forward(ctx, pos, dts, lengths, slope, eps, n_layers, w1, b1, w2, b2, *lw):
+    def forward(ctx, pos, dts, lengths, slope, eps, n_layers, drop, w1, b1, w2, b2, *lw):
         L_.require_cuda(pos, dts, w1, w2)
         pos, dts = pos.contiguous().float(), dts.contiguous().float()
         L, B = dts.shape
@@ -134,15 +133,20 @@ class CriticBodyBf16Fn(torch.autograd.Function):
             G = gemm_nt(x, wih, bias, None, 0, 0.0, label=f'bf16_pre_l{l}')                  # [M, nd*4H]
             c_all = torch.empty(M, nd * H, device=dev, dtype=torch.float32)
             h_all = torch.empty(M, nd * H, device=dev, dtype=BF16)
-            L_.call('gmt_bf16_lstm_layer_fwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(whh), L_.ptr(lengths),
-                    int(ragged), L, B, H, nd, L_.stream(), label='bf16_lstm_fwd', flops=2.0 * (L - 1) * B * nd * 4 * H * H)
+            # nn.LSTM's inter-layer dropout (RG.py:725): layer l also writes the masked copy of its output that layer l+1 reads
+            p_l = float(drop[0]) if l + 1 < n_layers else 0.0
+            h_drop = torch.empty(M, nd * H, device=dev, dtype=BF16) if p_l > 0 else None
+            L_.call('gmt_bf16_lstm_layer_fwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_drop), L_.ptr(whh),
+                    L_.ptr(lengths), int(ragged), L, B, H, nd, p_l, (int(drop[1]) + l + 1) & 0xFFFFFFFF, L_.stream(),
+                    label='bf16_lstm_fwd', flops=2.0 * (L - 1) * B * nd * 4 * H * H)
             saved_layers.append((x, G, c_all, h_all))
-            x = h_all
+            x = h_drop if p_l > 0 else h_all
+        x = h_all
         h_final = torch.cat([x[(L - 1) * B:, :H], x[:B, H:]], 1).float()
         if need_grad:
             ctx.save_for_backward(pos, dts, lengths, feat, w1, w2, *lw)
             ctx.bufs = (feat64, h1, saved_layers)
-        ctx.cfg = (float(slope), float(eps), int(n_layers), ragged, L, B, H, nd)
+        ctx.cfg = (float(slope), float(eps), int(n_layers), ragged, L, B, H, nd, (float(drop[0]), int(drop[1])))
         return h_final
 
     @staticmethod
@@ -152,13 +156,13 @@ class CriticBodyBf16Fn(torch.autograd.Function):
         pos, dts, lengths, feat, w1, w2, *lw = ctx.saved_tensors
         feat64, h1, saved_layers = ctx.bufs
         ctx.bufs = None
-        slope, eps, n_layers, ragged, L, B, H, nd = ctx.cfg
+        slope, eps, n_layers, ragged, L, B, H, nd, drop = ctx.cfg
         dev = pos.device
         M = L * B
         need = ctx.needs_input_grad
         need_in = need[0] or need[1]
-        need_w1, need_w2 = need[6] or need[7], need[8] or need[9]
-        need_lw = any(need[10:])
+        need_w1, need_w2 = need[7] or need[8], need[9] or need[10]
+        need_lw = any(need[11:])
         dh_final = dh_final.contiguous().float()
         dh_fin = torch.stack([dh_final[:, :H], dh_final[:, H:]], 0).contiguous()
         dcc = torch.empty(nd, B, H, device=dev, dtype=torch.float32)
@@ -169,8 +173,10 @@ class CriticBodyBf16Fn(torch.autograd.Function):
             x, G, c_all, h_all = saved_layers[l]
             ws = list(lw[4 * nd * l: 4 * nd * (l + 1)])
             wih, bias, whh, whhT, wihT = lstm_layer_weights(ws, H, nd)
+            p_l = drop[0] if l + 1 < n_layers else 0.0       # the mask layer l's output went through on its way up
             L_.call('gmt_bf16_lstm_layer_bwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(dh_out), L_.ptr(dh_fin), L_.ptr(dcc),
-                    L_.ptr(dhc), L_.ptr(whhT), L_.ptr(lengths), int(ragged), L, B, H, nd, L_.stream(),
+                    L_.ptr(dhc), L_.ptr(whhT), L_.ptr(lengths), int(ragged), L, B, H, nd, p_l,
+                    (drop[1] + l + 1) & 0xFFFFFFFF, L_.stream(),
                     label='bf16_lstm_bwd', flops=2.0 * (L - 1) * B * nd * 4 * H * H)
             dA = G                                                                             # [M, nd*4H] d(pre-activation)
             if need_lw:
@@ -212,8 +218,11 @@ class CriticBodyBf16Fn(torch.autograd.Function):
                     gpos, gdts = torch.empty_like(pos), torch.empty_like(dts)
                     L_.call('gmt_kinematics_bwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(gfeat), L_.ptr(gpos), L_.ptr(gdts),
                             L, B, eps, L_.stream(), nbytes=60.0 * M)
-        return (gpos, gdts, None, None, None, None, g_w1, g_b1, g_w2, g_b2, *grads_lw)
+        return (gpos, gdts, None, None, None, None, None, g_w1, g_b1, g_w2, g_b2, *grads_lw)
 
 
-def critic_body(pos, dts, lengths_i32, slope, eps, n_layers, w1, b1, w2, b2, lstm_weights):
-    return CriticBodyBf16Fn.apply(pos, dts, lengths_i32, slope, eps, n_layers, w1, b1, w2, b2, *lstm_weights)
+def critic_body(pos, dts, lengths_i32, slope, eps, n_layers, w1, b1, w2, b2, lstm_weights, drop=(0.0, 0)):
+    """drop = (p, seed): nn.LSTM's inter-layer dropout; the mask between layers l and l+1 is
+    ops.dropout_keep_mask(L, B, 2H, p, seed + l + 1, pair16=True)."""
+    return CriticBodyBf16Fn.apply(pos, dts, lengths_i32, slope, eps, n_layers, (float(drop[0]), int(drop[1])),
+                                  w1, b1, w2, b2, *lstm_weights)

@@ -39,7 +39,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define GMT_ERR_WORKSPACE (-4)    /* caller's workspace is too small                     */
 
 /* ABI version of this header; gmt_version() of the loaded library must match. */
-#define GMT_ABI_VERSION 5
+#define GMT_ABI_VERSION 6
 int gmt_version(void);
 
 /* ---- kinematic features, "mode A" ---------------------------------------------------
@@ -346,16 +346,20 @@ int gmt_bf16_gemm_nt(const void* A, long long lda, const void* W, long long ldw,
  *         same way by the caller);
  *   c_all [L][B][ndir*H] fp32 and h_all [L][B][ndir*H] bf16 (out), column d*H + u;  w_hh [ndir][4H slab order][H] bf16.
  * ragged != 0: lengths[b] <= L valid steps per row (direction 0 freezes the state of a finished row, so h_all[L-1] holds its
- * final state; direction 1 starts at t = lengths[b]-1 from zero state, final state = h_all[0]). */
-int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, const void* w_hh, const int* lengths, int ragged,
-                            int L, int B, int H, int ndir, hipStream_t stream);
+ * final state; direction 1 starts at t = lengths[b]-1 from zero state, final state = h_all[0]).
+ * drop_p > 0: h_drop [L][B][ndir*H] bf16 (out) = h_all after nn.LSTM's inter-layer dropout (RG.py:725) - the next layer's
+ * input; the mask is the counter-based function of (drop_seed, element index) the fp32 kernels use (gmt_keep16). */
+int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, void* h_drop, const void* w_hh, const int* lengths,
+                            int ragged, int L, int B, int H, int ndir, float drop_p, unsigned int drop_seed,
+                            hipStream_t stream);
 /* Backward sweep of the same layer (autograd's BPTT): gates is overwritten in place with d(pre-activation) - the dA that the
  * weight-gradient and input-gradient GEMMs then contract.  dh_out [L][B][ndir*H] bf16 or NULL: gradient of h_all from the layer
  * above; dh_fin [ndir][B][H] fp32: gradient of the two final hidden states; dc_carry (and, for ragged batches, dh_carry)
- * [ndir][B][H] fp32: scratch carried from launch to launch (no initialisation needed);  w_hhT [ndir][H][4H slab order] bf16. */
+ * [ndir][B][H] fp32: scratch carried from launch to launch (no initialisation needed);  w_hhT [ndir][H][4H slab order] bf16.
+ * drop_p > 0: dh_out is the gradient of the forward launch's h_drop; the same mask is applied to it on the way in. */
 int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const void* dh_out, const float* dh_fin, float* dc_carry,
                             float* dh_carry, const void* w_hhT, const int* lengths, int ragged, int L, int B, int H,
-                            int ndir, hipStream_t stream);
+                            int ndir, float drop_p, unsigned int drop_seed, hipStream_t stream);
 
 /* Weight gradients of the bf16 path: slabs[s][n][i] = sum over the s-th of n_slabs row ranges of dA[r][n] * X[r][i]
  * (autograd's dW = dA^T X for the LSTM and encoder weights; the caller sums the n_slabs fp32 partial results - deterministic).

@@ -6,7 +6,7 @@ from generative_mouse_trajectories_amd import _lib as L_
 DEV = torch.device('cuda:0')
 B, T, Hd = int(os.environ.get('B', 8192)), int(os.environ.get('T', 256)), 512
 cfg = gmt.Config(); cfg.discriminator_hidden_dim = Hd; cfg.generator_hidden_dim = 128; cfg.compute_dtype = 'bf16'
-cfg.lstm_dropout = 0.0
+cfg.lstm_dropout = float(os.environ.get('DROP', 0.1))
 torch.manual_seed(0)
 D = gmt.Discriminator(cfg).to(DEV).train()
 g = torch.Generator().manual_seed(1)

@@ -97,19 +97,19 @@ def test_bf16_lstm_layer_vs_torch_loop(L, B, Hd, ragged):
     c_all = torch.empty(L, B, 2 * Hd, device=DEV)
     h_all = torch.empty(L, B, 2 * Hd, device=DEV, dtype=BF)
     wpk = whh.detach()[:, perm, :].to(BF).contiguous()
-    L_.call('gmt_bf16_lstm_layer_fwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(wpk), L_.ptr(lengths), int(ragged),
-            L, B, Hd, 2, L_.stream())
+    L_.call('gmt_bf16_lstm_layer_fwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(h_all), None, L_.ptr(wpk), L_.ptr(lengths), int(ragged),
+            L, B, Hd, 2, 0.0, 0, L_.stream())
     hh = h_all.float()
     H.assert_close(hh * mask, h_ref.detach() * mask, 1e-2, 'h_all at the valid positions')
     H.assert_close(torch.stack([hh[L - 1, :, :Hd], hh[0, :, Hd:]]), fin_ref.detach(), 1e-2, 'final states')
     wT = whh.detach()[:, perm, :].transpose(1, 2).to(BF).contiguous()
     dcc = torch.empty(2, B, Hd, device=DEV); dhc = torch.empty(2, B, Hd, device=DEV)
     L_.call('gmt_bf16_lstm_layer_bwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(gh.contiguous()), L_.ptr(gfin), L_.ptr(dcc), L_.ptr(dhc),
-            L_.ptr(wT), L_.ptr(lengths), int(ragged), L, B, Hd, 2, L_.stream())
+            L_.ptr(wT), L_.ptr(lengths), int(ragged), L, B, Hd, 2, 0.0, 0, L_.stream())
     H.assert_close(G.float().view(L, B, 2, 4 * Hd), gpre[:, :, :, perm], 1e-2, 'd(pre-activation)')
 
 
-def _critic_case(Hd, Bs, T, seed, dt_scale, tol_fwd, tol_grad, checked=lambda k: True):
+def _critic_case(Hd, Bs, T, seed, dt_scale, tol_fwd, tol_grad, checked=lambda k: True, lstm_dropout=0.0):
     """Scores through the whole critic, and - through a fixed random linear functional of the final hidden states
     (RG.py:776-778), so that the comparison is not dominated by LeakyReLU sign flips in the small fp32 head - the
     gradients of every encoder / LSTM parameter and of the inputs, against the fp64 oracle."""
@@ -118,7 +118,8 @@ def _critic_case(Hd, Bs, T, seed, dt_scale, tol_fwd, tol_grad, checked=lambda k:
     cfg = gmt.Config()
     for k, v in over.items():
         setattr(cfg, k, v)
-    cfg.lstm_dropout = cfg.head_dropout = 0.0
+    cfg.head_dropout = 0.0
+    cfg.lstm_dropout = lstm_dropout
     cfg.compute_dtype = 'bf16'
     oc = O.OracleConfig(**over)
     pd, bd = PG.make_discriminator_params(oc, seed)
@@ -138,21 +139,28 @@ def _critic_case(Hd, Bs, T, seed, dt_scale, tol_fwd, tol_grad, checked=lambda k:
     lp1 = b['lengths'] + 1
     R = torch.randn(Bs, 2 * Hd, generator=torch.Generator().manual_seed(seed + 3))
 
+    from generative_mouse_trajectories_amd import ops
+    DSEED = 4242
+    masks = None
+    if lstm_dropout > 0:     # the kernels' counter-based mask, replayed on the host: [L, Bp, 2H] time-major -> the oracle's [B, L, 2H]
+        Bp = (Bs + 255) // 256 * 256
+        masks = [ops.dropout_keep_mask(T + 1, Bp, 2 * Hd, lstm_dropout, DSEED + 1, pair16=True)[:, :Bs].transpose(0, 1)]
+
     def oracle(dt):
         Pd = {k: H.t(v, dt).requires_grad_(True) for k, v in pd.items()}
         Bd = {k: H.t(v, dt) for k, v in bd.items()}
         tr, dr = traj.to(dt).requires_grad_(True), dts.to(dt).requires_grad_(True)
-        s, mid = O.discriminator_forward(Pd, Bd, tr, dr, lp1, training=True, return_intermediates=True)
+        s, mid = O.discriminator_forward(Pd, Bd, tr, dr, lp1, training=True, return_intermediates=True, lstm_dropout_masks=masks)
         keys = [k for k in Pd if not k.startswith('output_layers')]
         gs = torch.autograd.grad((mid['h_combined'] * R.to(dt)).sum(), [Pd[k] for k in keys] + [tr, dr])
         return s.detach(), mid['h_combined'].detach(), dict(zip(keys + ['d/d positions', 'd/d dts'], gs))
 
     s64, h64, g64 = oracle(torch.float64)
-    score = critic()(traj.to(DEV), dts.to(DEV), lp1.to(DEV)).detach()
+    score = critic()(traj.to(DEV), dts.to(DEV), lp1.to(DEV), dropout_seed=DSEED).detach()
     D = critic()
     D.output_layers = torch.nn.Sequential()              # the body alone: forward() then returns the final hidden states
     trajg, dtsg = traj.to(DEV).requires_grad_(True), dts.to(DEV).requires_grad_(True)
-    hf = D(trajg, dtsg, lp1.to(DEV))
+    hf = D(trajg, dtsg, lp1.to(DEV), dropout_seed=DSEED)
     (hf * R.to(DEV)).sum().backward()
     got = {k: p.grad for k, p in D.named_parameters()}
     got['d/d positions'], got['d/d dts'] = trajg.grad, dtsg.grad
@@ -175,6 +183,12 @@ def test_bf16_critic_vs_fp64_oracle_well_scaled():
 def test_bf16_critic_vs_fp64_oracle_config3_width():
     """H = 512 (config 3's width), 96 ragged rows, T = 32, well-scaled inputs."""
     _critic_case(512, 96, 32, 81, 50.0, 3e-2, 6e-2)
+
+
+def test_bf16_critic_with_interlayer_dropout_vs_fp64_oracle():
+    """nn.LSTM's inter-layer dropout (RG.py:725) as the counter-based mask inside the forward step kernel (second output
+    plane) and on the adjoint the backward step kernel receives; the oracle is handed the same mask."""
+    _critic_case(256, 160, 64, 101, 50.0, 3e-2, 6e-2, lstm_dropout=0.1)
 
 
 def test_bf16_critic_vs_fp64_oracle_raw_features():
