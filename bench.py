@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 B_LOCAL, T_STEPS, HID, LATENT = 4096, 128, 128, 64
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (the headline 5 PF figure is 2:1 sparse)
 # HBM bytes per launch from the PMC passes under profiles/ (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3
 # runs): known only for the kernel / shape that was counted
 PMC_TRAFFIC_BYTES = {('lstm_fwd_fused_I2', 4096): (4.81e9, 'profiles/r2_02_pmc_hbm.txt')}
@@ -124,7 +125,7 @@ def cpu_baseline(threads: int, B: int = 256):
             'note': 'cores = torch intra-op threads used (the GPU box grants this job 16 CPUs of the host)'}
 
 
-def kernel_table(prof, steps):
+def kernel_table(prof, steps, peak_tflops=PEAK_F32_MFMA_TFLOPS):
     """Per labelled kernel: launches and ms per step, achieved TFLOP/s or GB/s from the algorithmic work each call
     declared, fraction of the matching peak."""
     rows = {}
@@ -132,7 +133,7 @@ def kernel_table(prof, steps):
         r = {'launches_per_step': n / steps, 'ms_per_step': ms / steps, 'avg_launch_ms': ms / n}
         if fl > 0:
             r.update(bound='mfma', achieved=fl / (ms * 1e-3) / 1e12, unit='TFLOP/s')
-            r['frac'] = r['achieved'] / PEAK_F32_MFMA_TFLOPS
+            r['frac'] = r['achieved'] / peak_tflops
         elif by > 0:
             r.update(bound='hbm', achieved=by / (ms * 1e-3) / 1e9, unit='GB/s')
             r['frac'] = r['achieved'] / PEAK_HBM_GBS
@@ -140,10 +141,10 @@ def kernel_table(prof, steps):
     return rows
 
 
-def roofline_of_dominant(prof, steps, batch):
+def roofline_of_dominant(prof, steps, batch, peak_tflops=PEAK_F32_MFMA_TFLOPS):
     """The dominant kernel = the labelled HIP kernel with the largest summed duration in the timed region (ALL of
     them are candidates: recurrent sweeps, weight-gradient and input-gradient contractions, rollouts)."""
-    rows = kernel_table(prof, steps)
+    rows = kernel_table(prof, steps, peak_tflops)
     cand = {k: r for k, r in rows.items() if 'achieved' in r}
     if not cand:
         return None, rows
@@ -152,7 +153,7 @@ def roofline_of_dominant(prof, steps, batch):
     n, ms, fl, by = prof[name]
     pmc = PMC_TRAFFIC_BYTES.get((name, batch))
     roof = {'bound': r['bound'], 'kernel': name, 'achieved': r['achieved'],
-            'peak': PEAK_F32_MFMA_TFLOPS if r['bound'] == 'mfma' else PEAK_HBM_GBS, 'unit': r['unit'], 'frac': r['frac'],
+            'peak': peak_tflops if r['bound'] == 'mfma' else PEAK_HBM_GBS, 'unit': r['unit'], 'frac': r['frac'],
             'traffic': pmc[0] if pmc else None, 'traffic_unit': f'bytes/launch ({pmc[1]})' if pmc else None,
             'avg_launch_ms': ms / n, 'launches': n,
             'algorithmic_work_per_launch': (fl if fl > 0 else by) / n,
@@ -203,6 +204,66 @@ def bench_config5(args, dev):
     print(json.dumps(out), flush=True)
 
 
+def bench_config3(args, dev):
+    """BASELINE.json configs[2] (B=4096, T=256, H=512, bf16 operands / fp32 accumulation) - PARTIAL.  What exists at this
+    width is the critic (ops_bf16: forward, parameter and input gradients, inter-layer dropout); the generator rollout and
+    the gradient penalty's double backward are not built at H=512, so there is no trained-trajectories/s figure.  Timed here:
+    the critic's share of one D step - forward + backward with parameter gradients over real + fake = 2 x B trajectories of
+    257 points, 6 F_D of the 4 F_G + 8.375 F_D (= 55.19 GFLOP) a trained trajectory costs."""
+    import generative_mouse_trajectories_amd as gmt
+    from generative_mouse_trajectories_amd import _lib
+    B, T, Hd = args.batch, 256, 512
+    cfg = gmt.Config()
+    cfg.discriminator_hidden_dim, cfg.generator_hidden_dim, cfg.latent_dim = Hd, HID, LATENT
+    cfg.compute_dtype = 'bf16'
+    torch.manual_seed(0)
+    D = gmt.Discriminator(cfg).to(dev).train()
+    g = torch.Generator().manual_seed(1234)
+    rows = 2 * B                                                   # real + fake in one critic call, as the trainer does
+    pos = (torch.rand(1, rows, 2, generator=g) + torch.cumsum(torch.randn(T + 1, rows, 2, generator=g) * 0.01, 0)).to(dev)
+    dts = (torch.rand(T + 1, rows, generator=g) * 0.02 + 0.004).to(dev)
+    lens = torch.full((rows,), T + 1, dtype=torch.int32, device=dev)
+
+    def step():
+        D.zero_grad(set_to_none=True)
+        D.forward_tm(pos, dts, lens).mean().backward()
+
+    steps = args.steps if args.steps_given else 4
+    warm = args.warmup if args.warmup_given else 2
+    for _ in range(max(1, warm)):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_start()
+    step()
+    torch.cuda.synchronize()
+    prof = _lib.profile_stop()
+    roof, table = roofline_of_dominant(prof, 1, rows, PEAK_BF16_MFMA_TFLOPS)
+    torch.cuda.synchronize()
+    _lib.profile_start(only=[roof['kernel']])
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    roof_timed, _ = roofline_of_dominant(_lib.profile_stop(), steps, rows, PEAK_BF16_MFMA_TFLOPS)
+    roof_timed['all_kernels_ms_per_step'] = roof['all_kernels_ms_per_step']
+    d_tok = 2 * (9 * Hd + Hd * Hd) + 32 * Hd * Hd + 48 * Hd * Hd
+    F_D = (T + 1) * d_tok + 2 * (2 * Hd * Hd + Hd * Hd / 2 + Hd / 2)
+    flops = 3.0 * F_D * rows
+    out = {'metric': 'config 3 PARTIAL: critic forward + backward (parameter gradients) over real + fake, trajectories/s',
+           'value': rows / dt, 'unit': 'critic trajectories/s', 'complete_train_step': False, 'n_gpus': 1, 'steps': steps,
+           'warmup': warm, 'ms_per_step': dt * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'bf16 operands / f32 accumulate, state and parameter gradients', 'data': 'synthetic',
+           'config': {'workload': f'BASELINE configs[2] critic share of a D step: Discriminator (H={Hd}, 2-layer BiLSTM, '
+                                  f'lstm_dropout {cfg.lstm_dropout}) forward + backward on {rows} trajectories x {T + 1} points',
+                      'global_batch': B, 'seq_len': T, 'not_built_at_this_width': ['generator rollout + BPTT', 'gradient penalty']},
+           'algorithmic_tflop_per_step': flops / 1e12, 'step_tflops': flops / dt / 1e12,
+           'frac_of_bf16_mfma_peak': flops / dt / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+           'share_of_a_trained_trajectory': '6 F_D of 4 F_G + 8.375 F_D = 33.17 of 55.19 GFLOP',
+           'roofline': roof_timed, 'kernels': table, 'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated() / 1e9}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     if os.environ.get('GMT_DEBUG_HANG'):              # diagnosis aid: dump every thread's stack if the run stalls
         import faulthandler
@@ -212,7 +273,7 @@ def main():
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--batch', type=int, default=B_LOCAL)
-    ap.add_argument('--config', type=int, default=2, choices=(2, 5),
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3, 5),
                     help='BASELINE.json configs[] entry (1-based): 2 = train step, 5 = sampling + recompute')
     ap.add_argument('--samples', type=int, default=131072, help='config 5: trajectories per launch group')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -233,6 +294,8 @@ def main():
     dev = torch.device('cuda', local_rank)
     if args.config == 5:
         return bench_config5(args, dev)
+    if args.config == 3:
+        return bench_config3(args, dev)
     pg = None
     force_dist = bool(os.environ.get('GMT_FORCE_DIST'))      # exercise the RCCL path with one rank
     if world > 1 or force_dist:
