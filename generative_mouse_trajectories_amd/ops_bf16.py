@@ -150,6 +150,7 @@ class CriticBodyBf16Fn(torch.autograd.Function):
         return h_final
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # a create_graph=True pass (the gradient penalty) must fail loudly here
     def backward(ctx, dh_final):
         if ctx.bufs is None:
             raise L_.GmtError('bf16 critic body: backward called twice (the saved gate buffers were consumed in place)')

@@ -199,3 +199,19 @@ def test_bf16_critic_vs_fp64_oracle_raw_features():
     Asserted here: scores and final states to 1e-1, the gradients of layer 1 and of the inputs to 2e-1; the layer-0 /
     encoder gradients are printed, not asserted (measured 0.05 - 0.7 of the max-norm)."""
     _critic_case(256, 160, 64, 71, 1.0, 1e-1, 2e-1, checked=lambda k: '_l1' in k or k.startswith('d/d'))
+
+
+def test_bf16_critic_refuses_double_backward():
+    """The gradient penalty differentiates through the critic's backward pass (RG.py:829-835, create_graph=True); that sweep is
+    not built for the bf16 path, and it must say so instead of returning a silent zero."""
+    import generative_mouse_trajectories_amd as gmt
+    cfg = gmt.Config()
+    cfg.discriminator_hidden_dim, cfg.generator_hidden_dim, cfg.compute_dtype = 256, 32, 'bf16'
+    D = gmt.Discriminator(cfg).to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    traj = torch.rand(8, 17, 2, generator=g).to(DEV).requires_grad_(True)
+    dts = (torch.rand(8, 17, generator=g) * 0.5 + 0.1).to(DEV).requires_grad_(True)
+    score = D(traj, dts, torch.full((8,), 17, device=DEV))
+    grads, = torch.autograd.grad(score.sum(), [traj], create_graph=True)
+    with pytest.raises(RuntimeError):
+        ((grads.flatten(1).norm(dim=1) - 1) ** 2).mean().backward()
