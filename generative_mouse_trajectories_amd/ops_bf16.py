@@ -111,18 +111,22 @@ class CriticBodyBf16Fn(torch.autograd.Function):
         # The first Linear's K is 9, its K tile 64: the spare slots carry the bf16 round-off of the features and of the
         # weights (x = x_hi + x_lo, w = w_hi + w_lo; slots 0-8 x_hi w_hi, 9-17 x_lo w_hi, 18-26 x_hi w_lo), so that layer
         # is computed to ~16 bits at no cost - the raw features span 1e-4 ... 1e4 (clamped jerk), too wide for 8 bits.
+        # (The buffer is 256 wide - one weight-gradient tile - with a column of ones at 27: dW1 and db1 then come out of ONE
+        # gmt_bf16_wgrad_tn call in the backward pass; the forward GEMM reads the first 64 columns through the row stride.)
         f2 = feat.view(M, 9)
         f_hi = f2.to(BF16)
-        feat64 = torch.zeros(M, 64, device=dev, dtype=BF16)
-        feat64[:, 0:9] = f_hi
-        feat64[:, 9:18] = (f2 - f_hi.float()).to(BF16)
-        feat64[:, 18:27] = f_hi
+        featw = torch.zeros(M, 256, device=dev, dtype=BF16)
+        featw[:, 0:9] = f_hi
+        featw[:, 9:18] = (f2 - f_hi.float()).to(BF16)
+        featw[:, 18:27] = f_hi
+        featw[:, 27] = 1.0
+        feat64 = featw[:, :64]
         w1d = w1.detach().float()
         w_hi = w1d.to(BF16)
         w1p = torch.zeros(H, 64, device=dev, dtype=BF16)
         w1p[:, 0:9] = w_hi
         w1p[:, 9:18] = w_hi
-        w1p[:, 18:27] = (w1d - w_hi.float()).to(BF16)
+        w1p[:, 18:27] = (w1d - w_hi.float()).to(BF16)          # (column 27 stays zero: the ones column does not reach h1)
         w2b = w2.detach().to(BF16).contiguous()
         h1 = gemm_nt(feat64, w1p, b1.detach().float().contiguous(), None, 1, slope, label='bf16_enc1')
         x = gemm_nt(h1, w2b, b2.detach().float().contiguous(), None, 1, slope, label='bf16_enc2')
@@ -145,7 +149,7 @@ class CriticBodyBf16Fn(torch.autograd.Function):
         h_final = torch.cat([x[(L - 1) * B:, :H], x[:B, H:]], 1).float()
         if need_grad:
             ctx.save_for_backward(pos, dts, lengths, feat, w1, w2, *lw)
-            ctx.bufs = (feat64, h1, saved_layers)
+            ctx.bufs = (featw, h1, saved_layers)
         ctx.cfg = (float(slope), float(eps), int(n_layers), ragged, L, B, H, nd, (float(drop[0]), int(drop[1])))
         return h_final
 
@@ -155,7 +159,7 @@ class CriticBodyBf16Fn(torch.autograd.Function):
         if ctx.bufs is None:
             raise L_.GmtError('bf16 critic body: backward called twice (the saved gate buffers were consumed in place)')
         pos, dts, lengths, feat, w1, w2, *lw = ctx.saved_tensors
-        feat64, h1, saved_layers = ctx.bufs
+        featw, h1, saved_layers = ctx.bufs
         ctx.bufs = None
         slope, eps, n_layers, ragged, L, B, H, nd, drop = ctx.cfg
         dev = pos.device
@@ -211,9 +215,9 @@ class CriticBodyBf16Fn(torch.autograd.Function):
                 w2T = w2.detach().t().to(BF16).contiguous()
                 d_pre1 = gemm_nt(d_pre2, w2T, None, h1, 2, slope, label='bf16_dx_enc2')       # [M, H]
                 if need_w1:
-                    gw = torch.mm(d_pre1.t(), feat64[:, :18]).float()                          # K = 9: 0.1 % of the FLOPs
+                    gw = wgrad_tn(d_pre1, featw, label='bf16_wgrad_enc1')                      # [H, 256]
                     g_w1 = (gw[:, :9] + gw[:, 9:18]).contiguous()                              # x_hi + x_lo
-                    g_b1 = d_pre1.sum(0, dtype=torch.float32)
+                    g_b1 = gw[:, 27].contiguous()                                              # the ones column
                 if need_in:
                     gfeat = torch.mm(d_pre1, w1.detach().to(BF16)).float().contiguous()        # [M, 9]
                     gpos, gdts = torch.empty_like(pos), torch.empty_like(dts)
