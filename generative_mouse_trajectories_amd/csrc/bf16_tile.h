@@ -19,6 +19,7 @@
 // (256 VGPRs), 8 fragment reads per 16 MFMAs.
 #pragma once
 #include "gmt_common.h"
+#include "bf16_maps.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -45,7 +46,7 @@ __device__ __forceinline__ void stage(const __bf16* __restrict__ g, long long ld
 #pragma unroll
     for (int j = 0; j < ROWS / (8 * NWAVES); ++j) {
         const int row = j * 8 * NWAVES + wave * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int chunk = gmt_bf16_maps::stage_src_chunk(row, lane & 7);
         const __bf16* src = g + (long long)row * ld + chunk * 8;
         char* dst = lds_tile + (j * 8 * NWAVES + wave * 8) * 128;     // wave-uniform; the DMA adds lane * 16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -64,7 +65,6 @@ __device__ __forceinline__ void mainloop(const __bf16* __restrict__ Pg, long lon
     constexpr int NWV = 2 * NWQ;
     const int wp = wave / NWQ, wq = wave % NWQ;
     const int lo = lane & 31, hi = lane >> 5;
-    const int swz = (lo >> 1) & 7;
     if (nk > 0) {
         stage<T::TP, NWV>(Pg, ldp, lds, wave, lane);
         stage<T::TQ, NWV>(Qg, ldq, lds + T::TP * 128, wave, lane);
@@ -84,7 +84,7 @@ __device__ __forceinline__ void mainloop(const __bf16* __restrict__ Pg, long lon
         // SIMD nothing else hides the LDS latency, and the compiler on its own reads, waits, computes, reads, ...
         bf16x8 pf[2][NPB], qf[2][NQB];
         auto read_frags = [&](int s, int set) {
-            const int off = ((2 * s + hi) ^ swz) << 4;
+            const int off = gmt_bf16_maps::stage_addr(lo, 2 * s + hi) - lo * 128;      // (row blocks are multiples of 32 rows: same XOR)
 #pragma unroll
             for (int i = 0; i < NPB; ++i) pf[set][i] = *reinterpret_cast<const bf16x8*>(pt + i * 32 * 128 + off);
 #pragma unroll
@@ -136,9 +136,7 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d)
 template <int ROWB> struct RowImage {
     static constexpr int CH = ROWB / 16;                 // chunks per row (8, 16 or 32)
     static constexpr int RPI = 64 / CH;                  // rows per wave-instruction
-    static __device__ __forceinline__ int addr(int row, int byte_off) {
-        return row * ROWB + ((((byte_off >> 4) ^ row) & (CH - 1)) << 4) + (byte_off & 15);
-    }
+    static __device__ __forceinline__ int addr(int row, int byte_off) { return gmt_bf16_maps::image_addr(ROWB, row, byte_off); }
     // rows [0, nrows) <- g + rowmap(row) * ld_bytes + colmap(chunk): colmap gives the global byte offset of the image's
     // 16-byte chunk `chunk` (identity * 16 for a contiguous row); nrows % (4 RPI) == 0
     template <class RowMap, class ColMap>
@@ -146,7 +144,7 @@ template <int ROWB> struct RowImage {
                                                   RowMap rowmap, ColMap colmap, int wave, int lane) {
         for (int inst = wave; inst < nrows / RPI; inst += 4) {
             const int row = inst * RPI + lane / CH;
-            const int chunk = (lane ^ row) & (CH - 1);
+            const int chunk = gmt_bf16_maps::image_src_chunk(ROWB, row, lane);
             const char* src = g + (long long)rowmap(row) * ld_bytes + colmap(chunk);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(lds + inst * 1024), 16, 0, 0);
@@ -157,7 +155,7 @@ template <int ROWB> struct RowImage {
                                                     RowMap rowmap, ColMap colmap, int wave, int lane) {
         for (int inst = wave; inst < nrows / RPI; inst += 4) {
             const int row = inst * RPI + lane / CH;
-            const int chunk = (lane ^ row) & (CH - 1);
+            const int chunk = gmt_bf16_maps::image_src_chunk(ROWB, row, lane);
             const f32x4 v = *reinterpret_cast<const f32x4*>(lds + inst * 1024 + lane * 16);
             *reinterpret_cast<f32x4*>(g + (long long)rowmap(row) * ld_bytes + colmap(chunk)) = v;
         }
@@ -174,42 +172,7 @@ template <int ROWB> struct RowImage {
     }
 };
 
-// Workgroups of one launch that share an XCD (blockIdx % 8) and its L2 take a compact patch of the tile grid:
-// (n_mt / 4) row tiles x (n_pt / 2) weight tiles per direction, instead of one weight tile and every row tile.
-__device__ __forceinline__ void patch_of_block(int bid, int nblocks, int n_mt, int n_pt, int& d, int& pt, int& mt)
-{
-    const int per_dir = n_mt * n_pt;
-    if ((n_mt & 3) == 0 && (n_pt & 1) == 0 && (nblocks & 7) == 0) {
-        const int x = bid & 7, i = bid >> 3;
-        const int A = n_mt >> 2, Bp = n_pt >> 1;
-        d = i / (A * Bp);
-        const int r = i % (A * Bp);
-        pt = (x & 1) * Bp + r % Bp;
-        mt = (x >> 1) * A + r / Bp;
-    } else {
-        d = bid / per_dir;
-        const int rem = bid % per_dir;
-        pt = rem % n_pt;
-        mt = rem / n_pt;
-    }
-}
-
-// Tile order: blocks that run together on one XCD (blockIdx % 8) take consecutive tiles of a 4 (Q) x 8 (P) patch,
-// so the 32 CUs of an XCD share 4 activation tiles and 8 weight tiles in their L2 at any time.
-// n_p, n_q: tile counts; returns false for the blocks beyond the grid (none when the grid is exact).
-__device__ __forceinline__ void tile_of_block(long long bid, long long nblocks, int n_p, long long n_q, int& tp, long long& tq)
-{
-    long long lin = bid;
-    if ((nblocks & 7) == 0) lin = (bid & 7) * (nblocks >> 3) + (bid >> 3);
-    if ((n_q & 3) == 0) {
-        const long long per_group = 4LL * n_p;
-        const long long grp = lin / per_group, idx = lin % per_group;
-        tp = (int)(idx >> 2);
-        tq = grp * 4 + (idx & 3);
-    } else {
-        tp = (int)(lin % n_p);
-        tq = lin / n_p;
-    }
-}
+using gmt_bf16_maps::tile_of_block;      // GEMM tile order and the recurrence steps' XCD-compact patches: bf16_maps.h
+using gmt_bf16_maps::patch_of_block;
 
 }  // namespace gmt_bf16

@@ -106,7 +106,7 @@ __device__ __forceinline__ void stage_rows(const __bf16* __restrict__ g, long lo
 #pragma unroll
     for (int j = 0; j < BK / 8; ++j) {                          // 8 rows (4 waves x 2) per round
         const int row = j * 8 + wave * 2 + (lane >> 5);
-        const int chunk = (lane & 31) ^ ((row & 3) << 2);
+        const int chunk = gmt_bf16_maps::wg_src_chunk(row, lane & 31);
         const __bf16* src = g + (long long)row * ld + chunk * 8;
         char* dst = lds_tile + (j * 8 + wave * 2) * WG_ROWB;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -120,14 +120,12 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 // fragment of column block cb (32 columns) for k-step s (16 rows): lane (lo, hi) gets rows 16 s + 8 hi + 0..7 of column lo
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int col0, int s, int lane)
 {
-    const int grp = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const int col = col0 + 16 * (grp & 1) + 4 * p;             // first of the 4 columns this lane addresses
-    const int chunk = col >> 3, sub = (col & 7) * 2;
     s16x4 h[2];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        const int row = 16 * s + 8 * (grp >> 1) + 4 * half + q;
-        const char* a = tile + row * WG_ROWB + ((chunk ^ ((row & 3) << 2)) << 4) + sub;
+        int row, col;                                           // the row and first of 4 columns this lane addresses
+        gmt_bf16_maps::wg_tr_lane(lane, col0, s, half, row, col);
+        const char* a = tile + gmt_bf16_maps::wg_addr(row, col);
         h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
     }
     s16x8 v = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
