@@ -20,6 +20,11 @@ GMT_HD int stage_src_chunk(int row, int pos) { return pos ^ ((row >> 1) & 7); }
 // byte address (within the stage) of global chunk c of row r
 GMT_HD int stage_addr(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// ---- the same with 32 k per stage (64-byte rows, 4 chunks; a wave-instruction covers 16 rows): position p of row r holds
+// global chunk p ^ ((r >> 2) & 3) - the 16 rows of a ds_read_b128 lane group then fill one 256-byte bank row exactly.
+GMT_HD int stage32_src_chunk(int row, int pos) { return pos ^ ((row >> 2) & 3); }
+GMT_HD int stage32_addr(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
 // ---- epilogue row images: [rows][ROWB bytes], chunk c of row r at position c ^ (r & (ROWB/16 - 1))
 GMT_HD int image_src_chunk(int rowb, int row, int lane) { return (lane ^ row) & (rowb / 16 - 1); }
 GMT_HD int image_addr(int rowb, int row, int byte_off)

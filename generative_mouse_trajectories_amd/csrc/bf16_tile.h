@@ -107,6 +107,63 @@ __device__ __forceinline__ void mainloop(const __bf16* __restrict__ Pg, long lon
     }
 }
 
+// The same contraction with 32-deep K tiles (two LDS buffers of half the size): for kernels that want TWO workgroups per CU,
+// so that one's epilogue (HBM traffic) runs under the other's MFMAs.  4 waves (2 x 2), tile (64 NPB) x (64 NQB).
+template <int ROWS>
+__device__ __forceinline__ void stage32(const __bf16* __restrict__ g, long long ld, char* lds_tile, int wave, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < ROWS / 64; ++j) {
+        const int row = j * 64 + wave * 16 + (lane >> 2);
+        const int chunk = gmt_bf16_maps::stage32_src_chunk(row, lane & 3);
+        const __bf16* src = g + (long long)row * ld + chunk * 8;
+        char* dst = lds_tile + (j * 64 + wave * 16) * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+template <int NPB, int NQB>
+__device__ __forceinline__ void mainloop32(const __bf16* __restrict__ Pg, long long ldp, const __bf16* __restrict__ Qg,
+                                           long long ldq, int nk32, char* lds, f32x16 (&acc)[NPB][NQB], int wave, int lane)
+{
+    constexpr int TPr = 64 * NPB, TQr = 64 * NQB, STG = (TPr + TQr) * 64;
+    const int wp = wave >> 1, wq = wave & 1;
+    const int lo = lane & 31, hi = lane >> 5;
+    if (nk32 > 0) {
+        stage32<TPr>(Pg, ldp, lds, wave, lane);
+        stage32<TQr>(Qg, ldq, lds + TPr * 64, wave, lane);
+    }
+    for (int t = 0; t < nk32; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* cur = lds + (t & 1) * STG;
+        if (t + 1 < nk32) {
+            char* nxt = lds + ((t + 1) & 1) * STG;
+            stage32<TPr>(Pg + (long long)(t + 1) * 32, ldp, nxt, wave, lane);
+            stage32<TQr>(Qg + (long long)(t + 1) * 32, ldq, nxt + TPr * 64, wave, lane);
+        }
+        const char* pt = cur + (wp * (TPr / 2) + lo) * 64;
+        const char* qt = cur + TPr * 64 + (wq * (TQr / 2) + lo) * 64;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int off = gmt_bf16_maps::stage32_addr(lo, 2 * s + hi) - lo * 64;
+            bf16x8 pf[NPB], qf[NQB];
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) pf[i] = *reinterpret_cast<const bf16x8*>(pt + i * 32 * 64 + off);
+#pragma unroll
+            for (int j = 0; j < NQB; ++j) qf[j] = *reinterpret_cast<const bf16x8*>(qt + j * 32 * 64 + off);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+#pragma unroll
+                for (int j = 0; j < NQB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+}
+
 template <int NPB, int NQB>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NPB][NQB])
 {

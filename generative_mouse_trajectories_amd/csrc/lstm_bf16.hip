@@ -23,9 +23,13 @@ namespace {
 
 using namespace gmt_bf16;
 
-// LDS of the forward step: the mainloop's two stages (128 KiB), reused by the epilogue for half a tile at a time
-// (128 rows): pre-activations / gates [128][512 B], cell state [128][256 B], h [128][128 B] = 112 KiB.
-constexpr int FWD_G_OFF = 0, FWD_C_OFF = 128 * 512, FWD_H_OFF = FWD_C_OFF + 128 * 256, FWD_HD_OFF = FWD_H_OFF + 128 * 128;
+// Forward step: 256 (gate columns = 64 units x 4 gates) x 128 (rows) tiles, 32-deep K stages (48 KiB) and an epilogue that
+// handles one accumulator block column (64 rows) at a time in 64 KiB of LDS: TWO workgroups per CU, so that one's epilogue -
+// the step is as much HBM traffic as matrix work: 15 KB per row-step-direction - runs under the other's MFMAs.
+// Epilogue images: pre-activations / gates [64][512 B], cell state [64][256 B], h [64][128 B], dropped h [64][128 B].
+constexpr int FWD_TQ = 128;
+constexpr int FWD_G_OFF = 0, FWD_C_OFF = 64 * 512, FWD_H_OFF = FWD_C_OFF + 64 * 256, FWD_HD_OFF = FWD_H_OFF + 64 * 128;
+constexpr int FWD_LDS = FWD_HD_OFF + 64 * 128;                 // 64 KiB (>= the mainloop's 2 x 24 KiB)
 
 // keep-and-scale of 4 consecutive elements starting at idx (idx % 4 == 0) of the inter-layer dropout mask (RG.py:725): the
 // same function of (seed, element index in [L][B][ndir*H]) as the fp32 path's gmt_keep16, so ops.dropout_keep_mask replays it
@@ -39,7 +43,7 @@ __device__ __forceinline__ void drop4(float (&v)[4], uint32_t idx, uint32_t seed
 }
 
 template <bool RAGGED>
-__global__ __launch_bounds__(NTHREADS)
+__global__ __launch_bounds__(NTHREADS, 2)
 void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf16* __restrict__ Hall,
                           __bf16* __restrict__ Hdrop, const __bf16* __restrict__ Whh, const int* __restrict__ lengths,
                           int L, int B, int H, int ndir, int step, int n_mt, int n_pt, float drop_p, uint32_t drop_seed)
@@ -53,91 +57,89 @@ void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf
     const int tprev = d == 0 ? t - 1 : t + 1;
     const bool has_prev = step > 0;
     const long long ldg = (long long)ndir * 4 * H, ldh = (long long)ndir * H;
+    const long long row0 = (long long)mt * FWD_TQ;
     // this tile's corner in the [B][..] planes of timestep t (and of the forward pass's predecessor)
-    char* Gt = (char*)(G + ((long long)t * B + (long long)mt * TQ) * ldg + (long long)d * 4 * H + pt * TP);
-    char* Ct = (char*)(Call + ((long long)t * B + (long long)mt * TQ) * ldh + (long long)d * H + pt * (TP / 4));
-    char* Ht = (char*)(Hall + ((long long)t * B + (long long)mt * TQ) * ldh + (long long)d * H + pt * (TP / 4));
-    char* Hdt = Hdrop ? (char*)(Hdrop + ((long long)t * B + (long long)mt * TQ) * ldh + (long long)d * H + pt * (TP / 4)) : nullptr;
+    char* Gt = (char*)(G + ((long long)t * B + row0) * ldg + (long long)d * 4 * H + pt * TP);
+    char* Ct = (char*)(Call + ((long long)t * B + row0) * ldh + (long long)d * H + pt * (TP / 4));
+    char* Ht = (char*)(Hall + ((long long)t * B + row0) * ldh + (long long)d * H + pt * (TP / 4));
+    char* Hdt = Hdrop ? (char*)(Hdrop + ((long long)t * B + row0) * ldh + (long long)d * H + pt * (TP / 4)) : nullptr;
     const uint32_t thresh16 = (uint32_t)(drop_p * 65536.0f);
     const float keep_scale = 1.0f / (1.0f - drop_p);
-    const char* Cp = (const char*)(Call + ((long long)tprev * B + (long long)mt * TQ) * ldh + (long long)d * H + pt * (TP / 4));
-    const __bf16* Hp = Hall + ((long long)tprev * B + (long long)mt * TQ) * ldh + (long long)d * H;   // full-width rows
+    const char* Cp = (const char*)(Call + ((long long)tprev * B + row0) * ldh + (long long)d * H + pt * (TP / 4));
+    const __bf16* Hp = Hall + ((long long)tprev * B + row0) * ldh + (long long)d * H;   // full-width rows
 
-    f32x16 acc[4][4];
-    zero_acc<4, 4>(acc);
-    mainloop<4, 4>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H, Hp, ldh, has_prev ? H / BK : 0, lds, acc, wave, lane);
+    f32x16 acc[4][2];
+    zero_acc<4, 2>(acc);
+    mainloop32<4, 2>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H, Hp, ldh, has_prev ? H / 32 : 0, lds, acc, wave, lane);
 
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
     using GI = RowImage<512>;
     using CI = RowImage<256>;
     using HI = RowImage<128>;
+    const int rl = wq * 32 + lo;                                // image row of this lane in both halves
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        auto rowmap = [hf](int r) { return (r >> 6) * 128 + hf * 64 + (r & 63); };   // image row -> tile row
+    for (int j = 0; j < 2; ++j) {
+        auto rowmap = [j](int r) { return (r >> 5) * 64 + j * 32 + (r & 31); };   // image row -> tile row
+        const int brow = wq * 64 + j * 32 + lo;
         __syncthreads();                                        // the LDS is free (mainloop / previous half done)
-        GI::dma_in(Gt, ldg * 2, lds + FWD_G_OFF, 128, rowmap, wave, lane);
-        if (has_prev) CI::dma_in(Cp, ldh * 4, lds + FWD_C_OFF, 128, rowmap, wave, lane);
+        GI::dma_in(Gt, ldg * 2, lds + FWD_G_OFF, 64, rowmap, wave, lane);
+        if (has_prev) CI::dma_in(Cp, ldh * 4, lds + FWD_C_OFF, 64, rowmap, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        bool valid = true;
+        if (RAGGED) valid = t < lengths[row0 + brow];
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int j = 2 * hf + jj;
-            const int rl = wq * 64 + jj * 32 + lo;              // image row of this lane
-            bool valid = true;
-            if (RAGGED) valid = t < lengths[mt * TQ + wq * 128 + j * 32 + lo];
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int ucol = wp * 32 + 8 * g4 + 4 * hi;         // first of this lane's 4 units, within the tile's 64
+            bf16x4 pre[4];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int ucol = wp * 32 + 8 * g4 + 4 * hi;     // first of this lane's 4 units, within the tile's 64
-                bf16x4 pre[4];
+            for (int g = 0; g < 4; ++g)
+                pre[g] = *reinterpret_cast<const bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + g * 32 + 8 * g4 + 4 * hi) * 2));
+            f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+            if (has_prev) cp = *reinterpret_cast<const f32x4*>(lds + FWD_C_OFF + CI::addr(rl, ucol * 4));
+            float cn[4], hn[4], gi[4], gf[4], gg[4], go[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    pre[g] = *reinterpret_cast<const bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + g * 32 + 8 * g4 + 4 * hi) * 2));
-                f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-                if (has_prev) cp = *reinterpret_cast<const f32x4*>(lds + FWD_C_OFF + CI::addr(rl, ucol * 4));
-                float cn[4], hn[4], gi[4], gf[4], gg[4], go[4];
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e;
+                gi[e] = gmt_sigmoid(acc[0][j][r] + (float)pre[0][e]);
+                gf[e] = gmt_sigmoid(acc[1][j][r] + (float)pre[1][e]);
+                gg[e] = gmt_tanh(acc[2][j][r] + (float)pre[2][e]);
+                go[e] = gmt_sigmoid(acc[3][j][r] + (float)pre[3][e]);
+                cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
+                hn[e] = go[e] * gmt_tanh(cn[e]);
+            }
+            if (RAGGED) {
+                if (!valid) {                                   // frozen (direction 0) / not started (direction 1)
+                    bf16x4 hp = pack4(0.f, 0.f, 0.f, 0.f);
+                    if (d == 0 && has_prev)
+                        hp = *reinterpret_cast<const bf16x4*>(Hp + (long long)brow * ldh + pt * (TP / 4) + ucol);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g4 + e;
-                    gi[e] = gmt_sigmoid(acc[0][j][r] + (float)pre[0][e]);
-                    gf[e] = gmt_sigmoid(acc[1][j][r] + (float)pre[1][e]);
-                    gg[e] = gmt_tanh(acc[2][j][r] + (float)pre[2][e]);
-                    go[e] = gmt_sigmoid(acc[3][j][r] + (float)pre[3][e]);
-                    cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
-                    hn[e] = go[e] * gmt_tanh(cn[e]);
-                }
-                if (RAGGED) {
-                    if (!valid) {                               // frozen (direction 0) / not started (direction 1)
-                        bf16x4 hp = pack4(0.f, 0.f, 0.f, 0.f);
-                        if (d == 0 && has_prev)
-                            hp = *reinterpret_cast<const bf16x4*>(Hp + (long long)(wq * 128 + j * 32 + lo) * ldh + pt * (TP / 4) + ucol);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            cn[e] = d == 0 ? cp[e] : 0.f;
-                            hn[e] = (float)hp[e];
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        cn[e] = d == 0 ? cp[e] : 0.f;
+                        hn[e] = (float)hp[e];
                     }
                 }
-                if (!RAGGED || valid) {                         // (the pre-activations of a skipped row-step stay as they are)
-                    *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 0 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(gi[0], gi[1], gi[2], gi[3]);
-                    *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 1 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(gf[0], gf[1], gf[2], gf[3]);
-                    *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 2 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(gg[0], gg[1], gg[2], gg[3]);
-                    *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 3 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(go[0], go[1], go[2], go[3]);
-                }
-                f32x4 cv = {cn[0], cn[1], cn[2], cn[3]};
-                *reinterpret_cast<f32x4*>(lds + FWD_C_OFF + CI::addr(rl, ucol * 4)) = cv;
-                *reinterpret_cast<bf16x4*>(lds + FWD_H_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
-                if (Hdt) {                                      // the next layer's input: h after the inter-layer dropout
-                    const long long row = (long long)t * B + mt * TQ + wq * 128 + j * 32 + lo;
-                    drop4(hn, (uint32_t)(row * ldh + d * H + pt * (TP / 4) + ucol), drop_seed, thresh16, keep_scale);
-                    *reinterpret_cast<bf16x4*>(lds + FWD_HD_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
-                }
+            }
+            if (!RAGGED || valid) {                             // (the pre-activations of a skipped row-step stay as they are)
+                *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 0 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(gi[0], gi[1], gi[2], gi[3]);
+                *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 1 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(gf[0], gf[1], gf[2], gf[3]);
+                *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 2 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(gg[0], gg[1], gg[2], gg[3]);
+                *reinterpret_cast<bf16x4*>(lds + FWD_G_OFF + GI::addr(rl, (wp * 128 + 3 * 32 + 8 * g4 + 4 * hi) * 2)) = pack4(go[0], go[1], go[2], go[3]);
+            }
+            f32x4 cv = {cn[0], cn[1], cn[2], cn[3]};
+            *reinterpret_cast<f32x4*>(lds + FWD_C_OFF + CI::addr(rl, ucol * 4)) = cv;
+            *reinterpret_cast<bf16x4*>(lds + FWD_H_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
+            if (Hdt) {                                          // the next layer's input: h after the inter-layer dropout
+                const long long row = (long long)t * B + row0 + brow;
+                drop4(hn, (uint32_t)(row * ldh + d * H + pt * (TP / 4) + ucol), drop_seed, thresh16, keep_scale);
+                *reinterpret_cast<bf16x4*>(lds + FWD_HD_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
             }
         }
         __syncthreads();
-        GI::copy_out(Gt, ldg * 2, lds + FWD_G_OFF, 128, rowmap, wave, lane);
-        CI::copy_out(Ct, ldh * 4, lds + FWD_C_OFF, 128, rowmap, wave, lane);
-        HI::copy_out(Ht, ldh * 2, lds + FWD_H_OFF, 128, rowmap, wave, lane);
-        if (Hdt) HI::copy_out(Hdt, ldh * 2, lds + FWD_HD_OFF, 128, rowmap, wave, lane);
+        GI::copy_out(Gt, ldg * 2, lds + FWD_G_OFF, 64, rowmap, wave, lane);
+        CI::copy_out(Ct, ldh * 4, lds + FWD_C_OFF, 64, rowmap, wave, lane);
+        HI::copy_out(Ht, ldh * 2, lds + FWD_H_OFF, 64, rowmap, wave, lane);
+        if (Hdt) HI::copy_out(Hdt, ldh * 2, lds + FWD_HD_OFF, 64, rowmap, wave, lane);
     }
 }
 
@@ -290,13 +292,13 @@ extern "C" int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, v
     GMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (h_drop == nullptr) == (drop_p == 0.f));
     GMT_CHECK_ARG((long long)L * B * ndir * H < 0xffffffffLL);       // the mask's element counter is 32 bits
     GMT_CHECK_ARG(gates && c_all && h_all && w_hh && L >= 1 && (ndir == 1 || ndir == 2));
-    GMT_CHECK_ARG(B > 0 && B % TQ == 0 && H > 0 && (4 * H) % TP == 0 && H % BK == 0 && (!ragged || lengths));
-    const int n_mt = B / TQ, n_pt = 4 * H / TP;
+    GMT_CHECK_ARG(B > 0 && B % 256 == 0 && H > 0 && (4 * H) % TP == 0 && H % BK == 0 && (!ragged || lengths));
+    const int n_mt = B / FWD_TQ, n_pt = 4 * H / TP;
     auto k = ragged ? lstm_step_fwd_kernel<true> : lstm_step_fwd_kernel<false>;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS) != hipSuccess)
         return GMT_ERR_HIP;
     for (int step = 0; step < L; ++step)
-        hipLaunchKernelGGL(k, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), LDS_BYTES, stream, (__bf16*)gates, c_all, (__bf16*)h_all,
+        hipLaunchKernelGGL(k, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), FWD_LDS, stream, (__bf16*)gates, c_all, (__bf16*)h_all,
                            (__bf16*)h_drop, (const __bf16*)w_hh, lengths, L, B, H, ndir, step, n_mt, n_pt, drop_p, drop_seed);
     GMT_LAUNCH_CHECK();
     return GMT_OK;

@@ -33,6 +33,8 @@ void sim_adam(float* p, const float* g, float* m, float* v, long long n, float b
 // index maps of the bf16 kernels (csrc/bf16_maps.h)
 int sim_stage_src_chunk(int row, int pos) { return gmt_bf16_maps::stage_src_chunk(row, pos); }
 int sim_stage_addr(int row, int chunk) { return gmt_bf16_maps::stage_addr(row, chunk); }
+int sim_stage32_src_chunk(int row, int pos) { return gmt_bf16_maps::stage32_src_chunk(row, pos); }
+int sim_stage32_addr(int row, int chunk) { return gmt_bf16_maps::stage32_addr(row, chunk); }
 int sim_image_src_chunk(int rowb, int row, int lane) { return gmt_bf16_maps::image_src_chunk(rowb, row, lane); }
 int sim_image_addr(int rowb, int row, int off) { return gmt_bf16_maps::image_addr(rowb, row, off); }
 int sim_wg_src_chunk(int row, int pos) { return gmt_bf16_maps::wg_src_chunk(row, pos); }

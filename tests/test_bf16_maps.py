@@ -56,6 +56,24 @@ def test_operand_stage_image(sim):
                 assert _worst_way(addrs, 16, 64) == 1
 
 
+def test_half_depth_operand_stage_image(sim):
+    rows = 256
+    where = {}
+    for r0 in range(0, rows, 16):                     # one wave-instruction: 16 rows x 64 B
+        for lane in range(64):
+            row, pos = r0 + lane // 4, lane % 4
+            where[r0 * 64 + lane * 16] = (row, sim.sim_stage32_src_chunk(row, pos))
+    assert len(where) == rows * 4
+    for row in range(rows):
+        for c in range(4):
+            assert where[sim.sim_stage32_addr(row, c)] == (row, c)
+    for base in (0, 96):
+        for s in range(2):
+            for grp in B128_GROUPS:
+                addrs = [sim.sim_stage32_addr(base + (l & 31), 2 * s + (l >> 5)) for l in grp]
+                assert _worst_way(addrs, 16, 64) == 1
+
+
 @pytest.mark.parametrize('rowb', [128, 256, 512])
 def test_epilogue_row_images(sim, rowb):
     ch, rows = rowb // 16, 128
