@@ -39,6 +39,11 @@ class GenBwdArgs(ctypes.Structure):
                                                 ('seed', ctypes.c_uint)]
 
 
+class GenBf16Args(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in ('cond_pre', 'w0', 'w1', 'bias1', 'wh1', 'bh1', 'wh2', 'bh2', 'ends', 'target', 'tf_mask',
+                                   'out_seq', 'x0', 'x1', 'c0', 'c1', 'pos')] + [('T', c_i), ('B', c_i), ('H', c_i)]
+
+
 class SnFwdLayer(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ('w_orig', 'u', 'v', 'w_out', 'sigma', 'uv_saved')] + [('out_features', c_i), ('in_features', c_i)]
 
@@ -80,6 +85,7 @@ _SIGS = {
     'gmt_spectral_norm_fwd': [c_p, c_i, c_f, c_i, c_p],
     'gmt_spectral_norm_bwd': [c_p, c_i, c_p],
     'gmt_gen_rollout_fwd': [c_p, c_p],
+    'gmt_bf16_gen_rollout_fwd': [c_p, c_p],
     'gmt_gen_rollout_bwd': [c_p, c_p],
 }
 

@@ -105,8 +105,12 @@ class Generator(nn.Module):
         H = config.generator_hidden_dim
         if config.generator_num_layers != 2:
             raise NotImplementedError('the fused rollout kernel implements the reference default of 2 LSTM layers')
-        if H % 32 != 0 or H > 256:
-            raise NotImplementedError('generator_hidden_dim must be a multiple of 32, at most 256')
+        self.bf16 = getattr(config, 'compute_dtype', 'fp32') == 'bf16' and H > 256
+        if self.bf16:
+            if H != 512:
+                raise NotImplementedError('compute_dtype bf16: the generator rollout is built for generator_hidden_dim = 512')
+        elif H % 32 != 0 or H > 256:
+            raise NotImplementedError("generator_hidden_dim must be a multiple of 32, at most 256 (512: compute_dtype = 'bf16')")
         self.condition_encoder = nn.Sequential(
             nn.Linear(6 + config.latent_dim, H), nn.LayerNorm(H), nn.LeakyReLU(0.2),
             nn.Linear(H, H), nn.LayerNorm(H), nn.LeakyReLU(0.2))
@@ -134,6 +138,8 @@ class Generator(nn.Module):
         L_.require_cuda(start, end, z)
         H = self.config.generator_hidden_dim
         B = start.shape[0]
+        if self.bf16:
+            return self._rollout_bf16(start, end, z, target_tm, tf_mask, T, stop_distance, padded)
         Bp = ops.pad_rows(B)
         cond = self._compute_condition(start, end, z)
         lp = self.lstm
@@ -159,6 +165,30 @@ class Generator(nn.Module):
                                      torch.is_grad_enabled(), p_drop, dropout_seed, float(stop_distance), B, lens)
         if stop_distance > 0:
             return out[:, :B], lens[:B]
+        return out if padded else out[:, :B]
+
+    def _rollout_bf16(self, start, end, z, target_tm, tf_mask, T: int, stop_distance: float, padded: bool):
+        """H = 512 (BASELINE configs[2]): the no-grad rollout on the bf16 kernels (ops_bf16.gen_rollout; three launches per
+        timestep).  The training rollout (BPTT) is not built at this width."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('compute_dtype bf16, H = 512: only the no-grad rollout is built (wrap the call in '
+                                      'torch.no_grad(); the BPTT sweep at this width is not implemented)')
+        if stop_distance > 0:
+            raise NotImplementedError('compute_dtype bf16: the in-kernel early stop is not built; use generate(early_exit=False)')
+        if self.training and float(self.config.lstm_dropout) > 0:
+            raise NotImplementedError('compute_dtype bf16: the generator rollout runs without inter-layer dropout (eval mode)')
+        B = start.shape[0]
+        Bp = (B + ops_bf16.ROW_TILE - 1) // ops_bf16.ROW_TILE * ops_bf16.ROW_TILE
+        cond = _pad_batch(self._compute_condition(start, end, z), Bp, 0)
+        lp = self.lstm
+        if target_tm is not None:
+            target_tm = _pad_batch(target_tm, Bp, 1).contiguous()
+        out = ops_bf16.gen_rollout(cond, (lp.weight_ih_l0, lp.weight_hh_l0, lp.bias_ih_l0, lp.bias_hh_l0,
+                                          lp.weight_ih_l1, lp.weight_hh_l1, lp.bias_ih_l1, lp.bias_hh_l1),
+                                   (self.output_layer[0].weight, self.output_layer[0].bias,
+                                    self.output_layer[2].weight, self.output_layer[2].bias),
+                                   self.initial_input.reshape(3), _pad_batch(start, Bp, 0), _pad_batch(end, Bp, 0),
+                                   target_tm, tf_mask, T)
         return out if padded else out[:, :B]
 
     def forward_tm(self, start, end, z, target_sequences: torch.Tensor, tf_mask: Sequence[bool],

@@ -231,3 +231,61 @@ def critic_body(pos, dts, lengths_i32, slope, eps, n_layers, w1, b1, w2, b2, lst
     ops.dropout_keep_mask(L, B, 2H, p, seed + l + 1, pair16=True)."""
     return CriticBodyBf16Fn.apply(pos, dts, lengths_i32, slope, eps, n_layers, (float(drop[0]), int(drop[1])),
                                   w1, b1, w2, b2, *lstm_weights)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# generator rollout at H = 512, no-grad form (csrc/gen_bf16.hip)
+# ----------------------------------------------------------------------------------------------------------------------
+def gen_weights(w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, wh1):
+    """bf16 / slab-ordered forms of the generator's recurrent and head weights (cached until the parameters change)."""
+    H = w_hh0.shape[1]
+
+    def build():
+        p = slab_perm(H, w_hh0.device)
+        w_u = torch.cat([w_ih0[:, :3], w_ih0[:, 3 + H:]], 1)[p]                       # [4H, 7]: cur (3), dyn (4)
+        w0 = torch.zeros(4 * H, H + 64, device=w_hh0.device, dtype=torch.float32)
+        w0[:, :H] = w_hh0[p]
+        w0[:, H:H + 7] = w_u
+        w0[:, H + 7:H + 14] = w_u                                                     # the inputs' bf16 round-off rides here
+        w1 = torch.cat([w_ih1[p], w_hh1[p]], 1)
+        w_cond = w_ih0[:, 3:3 + H][p]
+        return (w0.to(BF16).contiguous(), w1.to(BF16).contiguous(), (b_ih1 + b_hh1)[p].float().contiguous(),
+                wh1.to(BF16).contiguous(), w_cond.to(BF16).contiguous(), (b_ih0 + b_hh0)[p].float().contiguous())
+    return ops.derived('bf16_gen', [w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, wh1], build)
+
+
+@torch.no_grad()
+def gen_rollout(cond, lstm_params, head, init_in, starts, ends, target_tm, tf_mask, T: int) -> torch.Tensor:
+    """cond [B, H] fp32 (condition encoder output), lstm_params = (w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1),
+    head = (W1 [H/2, H], b1, W2 [3, H/2], b2), init_in [3], starts / ends [B, 2], target_tm [T, B, 3] or None, tf_mask uint8
+    [T] (device) or None -> out [T, B, 3] fp32 (dx, dy, dt).  B % 256 == 0, H == 512."""
+    from ._lib import GenBf16Args
+    import ctypes
+    B, H = cond.shape
+    if H != 512 or B % ROW_TILE:
+        raise L_.GmtError(f'bf16 generator rollout: H={H} must be 512 and B={B} a multiple of {ROW_TILE}')
+    dev = cond.device
+    w0, w1, bias1, wh1, w_cond, bias0 = gen_weights(*lstm_params, head[0])
+    cond_pre = gemm_nt(cond.to(BF16).contiguous(), w_cond, bias0, None, 0, 0.0, label='bf16_gen_cond')       # [B, 4H]
+    x0 = torch.zeros(2, B, H + 64, device=dev, dtype=BF16)
+    rem = ends - starts
+    u0 = torch.cat([init_in.reshape(1, 3).expand(B, 3), rem, torch.sqrt((rem ** 2).sum(-1, keepdim=True) + 1e-8),
+                    torch.atan2(rem[:, 1:2], rem[:, 0:1])], 1).float()
+    u_hi = u0.to(BF16)
+    x0[0, :, H:H + 7] = u_hi
+    x0[0, :, H + 7:H + 14] = (u0 - u_hi.float()).to(BF16)
+    x1 = torch.zeros(2, B, 2 * H, device=dev, dtype=BF16)
+    c0 = torch.zeros(2, B, H, device=dev, dtype=torch.float32)
+    c1 = torch.zeros(2, B, H, device=dev, dtype=torch.float32)
+    pos = torch.stack([starts, starts], 0).float().contiguous()
+    out = torch.empty(T, B, 3, device=dev, dtype=torch.float32)
+    ends_c = ends.float().contiguous()
+    a = GenBf16Args()
+    keep = [cond_pre, w0, w1, bias1, wh1, head[1].detach().float().contiguous(), head[2].detach().float().contiguous(),
+            head[3].detach().float().contiguous(), ends_c, None if target_tm is None else target_tm.float().contiguous(), tf_mask]
+    (a.cond_pre, a.w0, a.w1, a.bias1, a.wh1, a.bh1, a.wh2, a.bh2, a.ends, a.target, a.tf_mask) = [L_.ptr(t) for t in keep]
+    a.out_seq, a.x0, a.x1, a.c0, a.c1, a.pos = (L_.ptr(t) for t in (out, x0, x1, c0, c1, pos))
+    a.T, a.B, a.H = T, B, H
+    g_exec = 2.0 * (4 * H * (H + 7) + 4 * H * 2 * H + (H // 2) * H + 3 * (H // 2))
+    L_.call('gmt_bf16_gen_rollout_fwd', ctypes.byref(a), L_.stream(), label='bf16_gen_rollout', flops=g_exec * T * B)
+    return out

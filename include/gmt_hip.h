@@ -367,6 +367,26 @@ int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const void* dh_out,
 int gmt_bf16_wgrad_tn(const void* dA, long long lda, const void* X, long long ldx, float* slabs,
                       long long M, int N, int I, int n_slabs, hipStream_t stream);
 
+/* Generator rollout at H = 512 (bf16 operands / fp32 accumulation), no-grad form: Generator.forward under torch.no_grad (the fake
+ * batch of a D step, RG.py:940-945) and Generator.generate (RG.py:606-690); three launches per timestep (csrc/gen_bf16.hip).
+ * Weights (bf16, 4H axis in the slab order of gmt_bf16_lstm_layer_fwd): w0 [4H][H+64] = [W_hh_l0 | W_u | W_u | 0] with W_u the
+ * 7 input columns (cur 3, dyn 4) of weight_ih_l0; w1 [4H][2H] = [W_ih_l1 | W_hh_l1]; wh1 [H/2][H] = output_layer.0.weight.
+ * cond_pre [B][4H] bf16 = condition W_cond^T + b_ih_l0 + b_hh_l0 (slab order; constant over time, RG.py:564-568).
+ * Workspace, caller-initialised: x0 [2][B][H+64] bf16 = zeros except x0[0][:, H:H+14] = the first step's 7 inputs as bf16 hi then
+ * lo parts (initial_input, end - start, its norm with eps 1e-8 inside the root, atan2); x1 [2][B][2H] bf16, c0 / c1 [2][B][H] fp32
+ * = zeros; pos [2][B][2] fp32 = starts twice (position, teacher-forced position).  B % 256 == 0, H == 512. */
+typedef struct gmt_bf16_gen_args {
+    const void* cond_pre; const void* w0; const void* w1; const float* bias1;
+    const void* wh1; const float* bh1; const float* wh2; const float* bh2;
+    const float* ends;            /* [B][2] */
+    const float* target;          /* [T][B][3] or NULL */
+    const unsigned char* tf_mask; /* [T] (device) or NULL: 1 = step t+1 is fed the target of step t (RG.py:588-595) */
+    float* out_seq;               /* [T][B][3] (dx, dy, dt) */
+    void* x0; void* x1; float* c0; float* c1; float* pos;
+    int T, B, H;
+} gmt_bf16_gen_args;
+int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* args, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -215,3 +215,44 @@ def test_bf16_critic_refuses_double_backward():
     grads, = torch.autograd.grad(score.sum(), [traj], create_graph=True)
     with pytest.raises(RuntimeError):
         ((grads.flatten(1).norm(dim=1) - 1) ** 2).mean().backward()
+
+
+def _generator_case(Bs, T, seed, tf_mask):
+    import generative_mouse_trajectories_amd as gmt
+    over = dict(latent_dim=16, generator_hidden_dim=512, discriminator_hidden_dim=32)
+    cfg = gmt.Config()
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    cfg.compute_dtype = 'bf16'
+    G = gmt.Generator(cfg)
+    pg = PG.make_generator_params(O.OracleConfig(**over), seed)
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in pg.items()}, strict=True)
+    G = G.to(DEV).eval()
+    b = H.batch_t(Bs, T, seed + 1, [T] * Bs, torch.float32)
+    z = torch.randn(Bs, 16, generator=torch.Generator().manual_seed(seed + 2))
+    with torch.no_grad():
+        out, _ = G(b['starts'].to(DEV), b['ends'].to(DEV), z.to(DEV), b['sequences'].to(DEV), tf_mask=tf_mask)
+    P64 = {k: H.t(v, torch.float64) for k, v in pg.items()}
+    ref = O.generator_forward(P64, b['starts'].double(), b['ends'].double(), z.double(), b['sequences'].double(), tf_mask)
+    e = [H.relerr(out[:, :, k].cpu(), ref[:, :, k]) for k in range(3)]
+    print(f'bf16 generator H=512 B={Bs} T={T} tf={sum(tf_mask)}/{T}: dx {e[0]:.1e} dy {e[1]:.1e} dt {e[2]:.1e}')
+    return e
+
+
+def test_bf16_generator_rollout_vs_fp64_oracle():
+    """Generator.forward under no_grad at H = 512 on the bf16 kernels (three launches per timestep) against the fp64 oracle:
+    free-running and with a mixed teacher-forcing mask (RG.py:559-595).  The rollout feeds its own outputs back for T steps,
+    so the bar is per output channel, 3e-2 of the channel's max-norm."""
+    for tf in ([False] * 16, [True, False, True, True, False, False, True, False] * 2):
+        for e in _generator_case(40, 16, 111, tf):
+            assert e <= 3e-2
+
+
+def test_bf16_generator_refuses_the_training_rollout():
+    import generative_mouse_trajectories_amd as gmt
+    cfg = gmt.Config()
+    cfg.generator_hidden_dim, cfg.discriminator_hidden_dim, cfg.compute_dtype = 512, 32, 'bf16'
+    G = gmt.Generator(cfg).to(DEV).train()
+    s = torch.rand(4, 2, device=DEV)
+    with pytest.raises(NotImplementedError):
+        G(s, s + 0.1, torch.randn(4, cfg.latent_dim, device=DEV), torch.zeros(4, 8, 3, device=DEV))
