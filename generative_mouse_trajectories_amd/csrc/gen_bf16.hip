@@ -26,7 +26,7 @@ void gen_cell_kernel(const __bf16* __restrict__ W, const __bf16* __restrict__ X,
                      const __bf16* __restrict__ pre, const float* __restrict__ bias,
                      const float* __restrict__ c_prev, float* __restrict__ c_out,
                      __bf16* __restrict__ h0, long long ldh0, __bf16* __restrict__ h1, long long ldh1,
-                     int H, int n_mt, int n_pt)
+                     __bf16* __restrict__ gates_out, int H, int n_mt, int n_pt)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -48,6 +48,7 @@ void gen_cell_kernel(const __bf16* __restrict__ W, const __bf16* __restrict__ X,
     const char* Pt = pre ? (const char*)(pre + row0 * 4 * H + pt * TP) : nullptr;
     const char* Cp = (const char*)(c_prev + row0 * H + pt * (TP / 4));
     char* Co = (char*)(c_out + row0 * H + pt * (TP / 4));
+    char* Go = gates_out ? (char*)(gates_out + row0 * 4 * H + pt * TP) : nullptr;     // training: the activated gates, for BPTT
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         auto rowmap = [j](int r) { return (r >> 5) * 64 + j * 32 + (r & 31); };
@@ -77,14 +78,23 @@ void gen_cell_kernel(const __bf16* __restrict__ W, const __bf16* __restrict__ X,
             float hn[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                cn[e] = gmt_sigmoid(a[1][e]) * cp[e] + gmt_sigmoid(a[0][e]) * gmt_tanh(a[2][e]);
-                hn[e] = gmt_sigmoid(a[3][e]) * gmt_tanh(cn[e]);
+                a[0][e] = gmt_sigmoid(a[0][e]); a[1][e] = gmt_sigmoid(a[1][e]);
+                a[2][e] = gmt_tanh(a[2][e]);    a[3][e] = gmt_sigmoid(a[3][e]);
+                cn[e] = a[1][e] * cp[e] + a[0][e] * a[2][e];
+                hn[e] = a[3][e] * gmt_tanh(cn[e]);
+            }
+            if (Go) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<bf16x4*>(lds + G_PRE_OFF + GI::addr(rl, (wp * 128 + g * 32 + 8 * g4 + 4 * hi) * 2)) =
+                        pack4(a[g][0], a[g][1], a[g][2], a[g][3]);
             }
             *reinterpret_cast<f32x4*>(lds + G_C_OFF + CI::addr(rl, ucol * 4)) = cn;
             *reinterpret_cast<bf16x4*>(lds + G_H_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
         }
         __syncthreads();
         CI::copy_out(Co, (long long)H * 4, lds + G_C_OFF, 64, rowmap, wave, lane);
+        if (Go) GI::copy_out(Go, 4LL * H * 2, lds + G_PRE_OFF, 64, rowmap, wave, lane);
         HI::copy_out((char*)(h0 + row0 * ldh0 + pt * (TP / 4)), ldh0 * 2, lds + G_H_OFF, 64, rowmap, wave, lane);
         if (h1) HI::copy_out((char*)(h1 + row0 * ldh1 + pt * (TP / 4)), ldh1 * 2, lds + G_H_OFF, 64, rowmap, wave, lane);
     }
@@ -97,6 +107,7 @@ struct head_args {
     const float* ends; const float* target; const unsigned char* tf_mask;
     float* out_seq; float* pos; float* tf_pos;
     __bf16* u_next; long long ldu;                   // &x0_next[0][H]: 14 slots written per row
+    __bf16* y_out; float* oraw_out;                  // training: [B][HH] head activation, [B] pre-softplus dt logit (or NULL)
     int t, B, H;
 };
 
@@ -133,6 +144,8 @@ void gen_head_kernel(head_args a)
                     const float v = acc[i][j][4 * g4 + e] + b[e];
                     y[e] = v > 0.f ? v : 0.2f * v;
                 }
+                if (a.y_out)
+                    *reinterpret_cast<bf16x4*>(a.y_out + (row0 + wq * 64 + j * 32 + lo) * HH + u) = pack4(y[0], y[1], y[2], y[3]);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const f32x4 w = *reinterpret_cast<const f32x4*>(w2s + k * HH + u);
@@ -156,6 +169,7 @@ void gen_head_kernel(head_args a)
         const float dt = (o2 > 20.f ? o2 : log1pf(expf(o2))) + 0.001f;                 // F.softplus, RG.py:577-580
         float* os = a.out_seq + ((long long)a.t * a.B + row) * 3;
         os[0] = o0; os[1] = o1; os[2] = dt;
+        if (a.oraw_out) a.oraw_out[row] = o2;
         float px = a.pos[row * 2] + o0, py = a.pos[row * 2 + 1] + o1;                  // RG.py:585
         float c0 = o0, c1 = o1, c2 = dt;
         if (a.target) {
@@ -177,6 +191,181 @@ void gen_head_kernel(head_args a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// BPTT of the rollout (autograd over RG.py:559-595), three launches per timestep in reverse order:
+//   book:   du_{t+1} = da0_{t+1} W_u (what step t+1's 7 inputs received) -> the gradients of the fed-back output and of the
+//           running position; total d out_t; head backward up to d(ypre_t)                                   (one wave a row)
+//   layer 1: dh1_t = d(ypre_t) W1 + da1_{t+1} W_hh_l1 -> cell backward -> da1_t        (two contractions into one accumulator)
+//   layer 0: dh0_t = da1_t W_ih_l1 + da0_{t+1} W_hh_l0 -> cell backward -> da0_t
+// The saved gates are overwritten in place by d(pre-activation); the weight gradients are dense GEMMs over all T*B
+// row-steps afterwards (gmt_bf16_wgrad_tn against the saved operands x0 / x1).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int GB_G_OFF = 0, GB_C_OFF = 64 * 512, GB_CP_OFF = GB_C_OFF + 64 * 256;          // as the critic's backward step
+constexpr int GB_LDS = 64 * 1024;
+
+__global__ __launch_bounds__(NTHREADS, 2)
+void gen_bwd_cell_kernel(const __bf16* __restrict__ P1, const __bf16* __restrict__ Q1, long long ldq1, int nk1,
+                         const __bf16* __restrict__ P2, const __bf16* __restrict__ Q2, long long ldq2, int nk2,
+                         __bf16* __restrict__ gates, const float* __restrict__ c_t, const float* __restrict__ c_prev,
+                         float* __restrict__ dc_carry, int has_next, int H, int n_mt, int n_pt)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using T = Tile<2, 2>;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int d, pt, mt;
+    patch_of_block(blockIdx.x, gridDim.x, n_mt, n_pt, d, pt, mt);
+    const long long row0 = (long long)mt * T::TQ;
+    f32x16 acc[2][2];
+    zero_acc<2, 2>(acc);
+    mainloop<2, 2>(P1 + (long long)pt * T::TP * (nk1 * BK), (long long)nk1 * BK, Q1 + row0 * ldq1, ldq1, nk1, lds, acc, wave, lane);
+    if (nk2 > 0) {
+        __syncthreads();                                        // the first contraction's last tile is read by everybody
+        mainloop<2, 2>(P2 + (long long)pt * T::TP * (nk2 * BK), (long long)nk2 * BK, Q2 + row0 * ldq2, ldq2, nk2, lds, acc, wave, lane);
+    }
+    char* Gt = (char*)(gates + row0 * 4 * H + pt * 512);
+    const char* Ct = (const char*)(c_t + row0 * H + pt * 128);
+    const char* Cp = (const char*)(c_prev + row0 * H + pt * 128);
+    float* dcc = dc_carry + row0 * H + pt * 128;
+
+    const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
+    using GI = RowImage<512>;
+    using CI = RowImage<256>;
+    const int rl = wq * 32 + lo;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        auto rowmap = [j](int r) { return (r >> 5) * 64 + j * 32 + (r & 31); };
+        const int brow = wq * 64 + j * 32 + lo;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            auto gcol = [i](int c) { return (((c >> 4) * 2 + i) * 128) * 2 + (c & 15) * 16; };
+            auto ccol = [i](int c) { return (((c >> 3) * 2 + i) * 32) * 4 + (c & 7) * 16; };
+            __syncthreads();
+            GI::dma_in(Gt, 4LL * H * 2, lds + GB_G_OFF, 64, rowmap, gcol, wave, lane);
+            CI::dma_in(Ct, (long long)H * 4, lds + GB_C_OFF, 64, rowmap, ccol, wave, lane);
+            CI::dma_in(Cp, (long long)H * 4, lds + GB_CP_OFF, 64, rowmap, ccol, wave, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int slab_u = (wp * 2 + i) * 32;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int u = slab_u + 8 * g4 + 4 * hi;
+                const long long co = (long long)brow * H + u;
+                f32x4 dc = {0.f, 0.f, 0.f, 0.f};
+                if (has_next) dc = *reinterpret_cast<const f32x4*>(dcc + co);
+                const int gbyte = wp * 256 + (8 * g4 + 4 * hi) * 2;
+                bf16x4 gt[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gt[g] = *reinterpret_cast<const bf16x4*>(lds + GB_G_OFF + GI::addr(rl, gbyte + g * 64));
+                const int cbyte = wp * 128 + (8 * g4 + 4 * hi) * 4;
+                const f32x4 c = *reinterpret_cast<const f32x4*>(lds + GB_C_OFF + CI::addr(rl, cbyte));
+                const f32x4 cp = *reinterpret_cast<const f32x4*>(lds + GB_CP_OFF + CI::addr(rl, cbyte));
+                float da[4][4];
+                f32x4 dcn;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dh = acc[i][j][4 * g4 + e];
+                    const float gi = (float)gt[0][e], gf = (float)gt[1][e], gg = (float)gt[2][e], go = (float)gt[3][e];
+                    const float tc = gmt_tanh(c[e]);
+                    const float dct = dc[e] + dh * go * (1.f - tc * tc);
+                    da[0][e] = dct * gg * gi * (1.f - gi);
+                    da[1][e] = dct * cp[e] * gf * (1.f - gf);
+                    da[2][e] = dct * gi * (1.f - gg * gg);
+                    da[3][e] = dh * tc * go * (1.f - go);
+                    dcn[e] = dct * gf;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<bf16x4*>(lds + GB_G_OFF + GI::addr(rl, gbyte + g * 64)) = pack4(da[g][0], da[g][1], da[g][2], da[g][3]);
+                *reinterpret_cast<f32x4*>(dcc + co) = dcn;
+            }
+            __syncthreads();
+            GI::copy_out(Gt, 4LL * H * 2, lds + GB_G_OFF, 64, rowmap, gcol, wave, lane);
+        }
+    }
+}
+
+// Bookkeeping + head backward of step t (t = -1: only the gradient of the first input).  One wave per row, 16 rows a block.
+struct book_args {
+    const __bf16* da0_next;     // [B][4H] d(pre-activation) of layer 0 at step t+1, or NULL (t = T-1)
+    const __bf16* w_u;          // [4H][8] bf16: W_u in slab row order, 8th column zero
+    const __bf16* u_next;       // &x0[t+1][0][H]: the 7 inputs of step t+1 as hi (0-6) and lo (7-13) parts, row stride ldu
+    long long ldu;
+    const float* d_out;         // [B][3] external gradient of out_t (NULL for t = -1)
+    const __bf16* y; const float* oraw; const float* wh2;       // [B][HH], [B], [3][HH]
+    float* p_carry;             // [B][2]: gradient of the position before step t+1 that flows on to step t+2 (in: P_{t+2}, out: P_{t+1})
+    __bf16* dypre; float* d_o;  // [B][HH] bf16, [B][3] fp32 out
+    float* d_in0;               // [B][3] out (t = -1 only)
+    int tf_t, tf_next;          // teacher-forcing flags of steps t and t+1 (host copies of the mask)
+    int t, B, H;
+};
+
+__global__ __launch_bounds__(NTHREADS)
+void gen_bwd_book_kernel(book_args a)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 wus[2048 * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int HH = a.H / 2, G4 = 4 * a.H;
+    if (a.da0_next)
+        for (int i = threadIdx.x; i < G4; i += NTHREADS)
+            *reinterpret_cast<bf16x8*>(wus + i * 8) = *reinterpret_cast<const bf16x8*>(a.w_u + (long long)i * 8);
+    __syncthreads();
+    for (int rr = 0; rr < 4; ++rr) {
+        const long long row = (long long)blockIdx.x * 16 + wave * 4 + rr;
+        float du[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (a.da0_next) {
+            const __bf16* dr = a.da0_next + row * G4;
+            for (int c = 0; c < G4 / 512; ++c) {                // 512 columns per pass: 8 per lane
+                const int k0 = c * 512 + lane * 8;
+                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dr + k0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bf16x8 w = *reinterpret_cast<const bf16x8*>(wus + (k0 + e) * 8);
+                    const float x = (float)dv[e];
+#pragma unroll
+                    for (int s2 = 0; s2 < 7; ++s2) du[s2] += x * (float)w[s2];
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 7; ++s2) du[s2] = gmt_wave_sum(du[s2]);
+        }
+        // gradient of the position before step t+1: through the dynamic features of step t+1, plus what flows on (RG.py:502-504, 585)
+        float px = 0.f, py = 0.f;
+        if (a.da0_next) {
+            const __bf16* un = a.u_next + row * a.ldu;
+            const float rx = (float)un[3] + (float)un[10], ry = (float)un[4] + (float)un[11], dist = (float)un[5] + (float)un[12];
+            const float r2 = rx * rx + ry * ry;
+            const float inv = r2 > 0.f ? 1.f / r2 : 0.f;
+            const float drx = du[3] + du[5] * rx / dist - du[6] * ry * inv;
+            const float dry = du[4] + du[5] * ry / dist + du[6] * rx * inv;
+            px = -drx; py = -dry;
+            if (!a.tf_next) { px += a.p_carry[row * 2]; py += a.p_carry[row * 2 + 1]; }
+        }
+        if (a.t < 0) {
+            if (lane == 0) { a.d_in0[row * 3] = du[0]; a.d_in0[row * 3 + 1] = du[1]; a.d_in0[row * 3 + 2] = du[2]; }
+            continue;
+        }
+        if (lane == 0) { a.p_carry[row * 2] = px; a.p_carry[row * 2 + 1] = py; }
+        float g0 = a.d_out[row * 3], g1 = a.d_out[row * 3 + 1], g2 = a.d_out[row * 3 + 2];
+        if (!a.tf_t) { g0 += du[0] + px; g1 += du[1] + py; g2 += du[2]; }          // cur_{t+1} = out_t, pos_{t+1} = pos_t + out_t[:2]
+        const float o2 = a.oraw[row];
+        const float do2 = g2 * (o2 > 20.f ? 1.f : 1.f / (1.f + expf(-o2)));        // softplus'
+        if (lane == 0) { a.d_o[row * 3] = g0; a.d_o[row * 3 + 1] = g1; a.d_o[row * 3 + 2] = do2; }
+        const int u0 = lane * 4;                                                    // HH = 256: 4 units a lane
+        const bf16x4 yv = *reinterpret_cast<const bf16x4*>(a.y + row * HH + u0);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.wh2 + u0);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.wh2 + HH + u0);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(a.wh2 + 2 * HH + u0);
+        float dp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dy = g0 * w0[e] + g1 * w1[e] + do2 * w2[e];
+            dp[e] = (float)yv[e] > 0.f ? dy : 0.2f * dy;
+        }
+        *reinterpret_cast<bf16x4*>(a.dypre + row * HH + u0) = pack4(dp[0], dp[1], dp[2], dp[3]);
+    }
+}
+
 }  // namespace
 
 extern "C" int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* a, hipStream_t stream)
@@ -184,32 +373,88 @@ extern "C" int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* a, hipStream_t 
     GMT_CHECK_ARG(a && a->cond_pre && a->w0 && a->w1 && a->bias1 && a->wh1 && a->bh1 && a->wh2 && a->bh2 && a->ends && a->out_seq);
     GMT_CHECK_ARG(a->x0 && a->x1 && a->c0 && a->c1 && a->pos && a->T >= 1);
     GMT_CHECK_ARG(a->H == 512 && a->B > 0 && a->B % 256 == 0 && (!a->tf_mask || a->target));
+    const bool train = a->gates0 != nullptr;        // training: every step keeps its state (x0 / x1 / c0 / c1 have T+1 slots)
+    GMT_CHECK_ARG(!train || (a->gates1 && a->y_all && a->oraw_all));
     const int H = a->H, B = a->B, K0 = H + 64, K1 = 2 * H;
+    const long long ld0 = train ? GMT_BF16_GEN_X0_TRAIN_WIDTH : K0;
     const int n_mt = B / G_TQ, n_pt = 4 * H / TP;
     if (hipFuncSetAttribute((const void*)gen_cell_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)gen_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess)
         return GMT_ERR_HIP;
     __bf16* x0 = (__bf16*)a->x0; __bf16* x1 = (__bf16*)a->x1;
     for (int t = 0; t < a->T; ++t) {
-        const int cur = t & 1, nxt = cur ^ 1;
-        __bf16* x0c = x0 + (size_t)cur * B * K0; __bf16* x0n = x0 + (size_t)nxt * B * K0;
-        __bf16* x1c = x1 + (size_t)cur * B * K1; __bf16* x1n = x1 + (size_t)nxt * B * K1;
+        const size_t cur = train ? t : (t & 1), nxt = train ? t + 1 : ((t & 1) ^ 1);
+        __bf16* x0c = x0 + cur * B * ld0; __bf16* x0n = x0 + nxt * B * ld0;
+        __bf16* x1c = x1 + cur * B * K1; __bf16* x1n = x1 + nxt * B * K1;
+        // state slots: c[cur] = state before step t, c[nxt] = after (ping-pong when not training)
+        __bf16* g0 = train ? (__bf16*)a->gates0 + (size_t)t * B * 4 * H : nullptr;
+        __bf16* g1 = train ? (__bf16*)a->gates1 + (size_t)t * B * 4 * H : nullptr;
         // layer 0: reads x0[cur] = [h0_{t-1} | u_t]; h0_t -> x0[nxt][:, :H] (next step's recurrence) and x1[cur][:, :H]
-        hipLaunchKernelGGL(gen_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), G_LDS, stream, (const __bf16*)a->w0, x0c, (long long)K0,
-                           K0 / 32, (const __bf16*)a->cond_pre, (const float*)nullptr, a->c0 + (size_t)nxt * B * H,
-                           a->c0 + (size_t)cur * B * H, x0n, (long long)K0, x1c, (long long)K1, H, n_mt, n_pt);
+        hipLaunchKernelGGL(gen_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), G_LDS, stream, (const __bf16*)a->w0, x0c, ld0,
+                           K0 / 32, (const __bf16*)a->cond_pre, (const float*)nullptr, a->c0 + cur * B * H,
+                           a->c0 + nxt * B * H, x0n, ld0, x1c, (long long)K1, g0, H, n_mt, n_pt);
         // layer 1: reads x1[cur] = [h0_t | h1_{t-1}]; h1_t -> x1[nxt][:, H:]
         hipLaunchKernelGGL(gen_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), G_LDS, stream, (const __bf16*)a->w1, x1c, (long long)K1,
-                           K1 / 32, (const __bf16*)nullptr, a->bias1, a->c1 + (size_t)nxt * B * H, a->c1 + (size_t)cur * B * H,
-                           x1n + H, (long long)K1, (__bf16*)nullptr, 0LL, H, n_mt, n_pt);
+                           K1 / 32, (const __bf16*)nullptr, a->bias1, a->c1 + cur * B * H, a->c1 + nxt * B * H,
+                           x1n + H, (long long)K1, (__bf16*)nullptr, 0LL, g1, H, n_mt, n_pt);
         head_args h;
         h.wh1 = (const __bf16*)a->wh1; h.bh1 = a->bh1; h.wh2 = a->wh2; h.bh2 = a->bh2;
         h.h = x1n + H; h.ldh = K1;
         h.ends = a->ends; h.target = a->target; h.tf_mask = a->tf_mask;
         h.out_seq = a->out_seq; h.pos = a->pos; h.tf_pos = a->pos + (size_t)B * 2;
-        h.u_next = x0n + H; h.ldu = K0;
+        h.u_next = x0n + H; h.ldu = ld0;
+        h.y_out = train ? (__bf16*)a->y_all + (size_t)t * B * (H / 2) : nullptr;
+        h.oraw_out = train ? a->oraw_all + (size_t)t * B : nullptr;
         h.t = t; h.B = B; h.H = H;
         hipLaunchKernelGGL(gen_head_kernel, dim3(B / G_TQ), dim3(NTHREADS), G_LDS, stream, h);
+    }
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+extern "C" int gmt_bf16_gen_rollout_bwd(const gmt_bf16_gen_bwd_args* a, hipStream_t stream)
+{
+    GMT_CHECK_ARG(a && a->gates0 && a->gates1 && a->c0 && a->c1 && a->x0 && a->y_all && a->oraw_all && a->d_out);
+    GMT_CHECK_ARG(a->w1T && a->whh1T && a->wih1T && a->whh0T && a->w_u && a->wh2 && a->dypre_all && a->d_o && a->d_in0);
+    GMT_CHECK_ARG(a->dc0 && a->dc1 && a->p_carry && a->tf_mask_host && a->H == 512 && a->B > 0 && a->B % 256 == 0 && a->T >= 1);
+    using T2 = Tile<2, 2>;
+    const int H = a->H, B = a->B, T = a->T, HH = H / 2;
+    const int n_mt = B / T2::TQ, n_pt = H / T2::TP;
+    if (hipFuncSetAttribute((const void*)gen_bwd_cell_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS) != hipSuccess)
+        return GMT_ERR_HIP;
+    const size_t ld0 = GMT_BF16_GEN_X0_TRAIN_WIDTH;
+    __bf16* g0 = (__bf16*)a->gates0; __bf16* g1 = (__bf16*)a->gates1;
+    const __bf16* x0 = (const __bf16*)a->x0;
+    for (int t = T - 1; t >= -1; --t) {
+        const bool has_next = t < T - 1;
+        book_args b;
+        b.da0_next = has_next ? g0 + (size_t)(t + 1) * B * 4 * H : nullptr;
+        b.w_u = (const __bf16*)a->w_u;
+        b.u_next = x0 + (size_t)(t + 1) * B * ld0 + H; b.ldu = (long long)ld0;
+        b.d_out = t >= 0 ? a->d_out + (size_t)t * B * 3 : nullptr;
+        b.y = t >= 0 ? (const __bf16*)a->y_all + (size_t)t * B * HH : nullptr;
+        b.oraw = t >= 0 ? a->oraw_all + (size_t)t * B : nullptr;
+        b.wh2 = a->wh2; b.p_carry = a->p_carry;
+        b.dypre = t >= 0 ? (__bf16*)a->dypre_all + (size_t)t * B * HH : nullptr;
+        b.d_o = t >= 0 ? a->d_o + (size_t)t * B * 3 : nullptr;
+        b.d_in0 = a->d_in0;
+        b.tf_t = t >= 0 ? a->tf_mask_host[t] : 0;
+        b.tf_next = has_next ? a->tf_mask_host[t + 1] : 0;
+        b.t = t; b.B = B; b.H = H;
+        hipLaunchKernelGGL(gen_bwd_book_kernel, dim3(B / 16), dim3(NTHREADS), 0, stream, b);
+        if (t < 0) break;
+        // layer 1: dh1_t = d(ypre_t) W1 + da1_{t+1} W_hh_l1
+        hipLaunchKernelGGL(gen_bwd_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), GB_LDS, stream,
+                           (const __bf16*)a->w1T, (const __bf16*)b.dypre, (long long)HH, HH / BK,
+                           (const __bf16*)a->whh1T, (const __bf16*)(g1 + (size_t)(has_next ? t + 1 : t) * B * 4 * H), 4LL * H,
+                           has_next ? 4 * H / BK : 0, g1 + (size_t)t * B * 4 * H, a->c1 + (size_t)(t + 1) * B * H,
+                           a->c1 + (size_t)t * B * H, a->dc1, (int)has_next, H, n_mt, n_pt);
+        // layer 0: dh0_t = da1_t W_ih_l1 + da0_{t+1} W_hh_l0
+        hipLaunchKernelGGL(gen_bwd_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), GB_LDS, stream,
+                           (const __bf16*)a->wih1T, (const __bf16*)(g1 + (size_t)t * B * 4 * H), 4LL * H, 4 * H / BK,
+                           (const __bf16*)a->whh0T, (const __bf16*)(g0 + (size_t)(has_next ? t + 1 : t) * B * 4 * H), 4LL * H,
+                           has_next ? 4 * H / BK : 0, g0 + (size_t)t * B * 4 * H, a->c0 + (size_t)(t + 1) * B * H,
+                           a->c0 + (size_t)t * B * H, a->dc0, (int)has_next, H, n_mt, n_pt);
     }
     GMT_LAUNCH_CHECK();
     return GMT_OK;

@@ -168,21 +168,31 @@ class Generator(nn.Module):
         return out if padded else out[:, :B]
 
     def _rollout_bf16(self, start, end, z, target_tm, tf_mask, T: int, stop_distance: float, padded: bool):
-        """H = 512 (BASELINE configs[2]): the no-grad rollout on the bf16 kernels (ops_bf16.gen_rollout; three launches per
-        timestep).  The training rollout (BPTT) is not built at this width."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('compute_dtype bf16, H = 512: only the no-grad rollout is built (wrap the call in '
-                                      'torch.no_grad(); the BPTT sweep at this width is not implemented)')
+        """H = 512 (BASELINE configs[2]): the rollout on the bf16 kernels, three launches per timestep
+        (ops_bf16.gen_rollout under no_grad, ops_bf16.GenRolloutBf16Fn with BPTT otherwise)."""
         if stop_distance > 0:
             raise NotImplementedError('compute_dtype bf16: the in-kernel early stop is not built; use generate(early_exit=False)')
         if self.training and float(self.config.lstm_dropout) > 0:
             raise NotImplementedError('compute_dtype bf16: the generator rollout runs without inter-layer dropout (eval mode)')
         B = start.shape[0]
+        H = self.config.generator_hidden_dim
         Bp = (B + ops_bf16.ROW_TILE - 1) // ops_bf16.ROW_TILE * ops_bf16.ROW_TILE
         cond = _pad_batch(self._compute_condition(start, end, z), Bp, 0)
         lp = self.lstm
         if target_tm is not None:
             target_tm = _pad_batch(target_tm, Bp, 1).contiguous()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training rollout: every step's state is kept, BPTT in ops_bf16.GenRolloutBf16Fn
+            w_ih0 = lp.weight_ih_l0
+            g0 = F.linear(cond, w_ih0[:, 3:3 + H], lp.bias_ih_l0 + lp.bias_hh_l0)
+            w_u = torch.cat([w_ih0[:, :3], w_ih0[:, 3 + H:]], dim=1)
+            tf_list = None if tf_mask is None else [bool(v) for v in tf_mask.tolist()]
+            out = ops_bf16.GenRolloutBf16Fn.apply(g0, w_u, lp.weight_hh_l0, lp.weight_ih_l1, lp.weight_hh_l1,
+                                                  lp.bias_ih_l1 + lp.bias_hh_l1, self.output_layer[0].weight,
+                                                  self.output_layer[0].bias, self.output_layer[2].weight,
+                                                  self.output_layer[2].bias, self.initial_input.reshape(3),
+                                                  _pad_batch(start, Bp, 0), _pad_batch(end, Bp, 0), target_tm, tf_list, T)
+            return out if padded else out[:, :B]
         out = ops_bf16.gen_rollout(cond, (lp.weight_ih_l0, lp.weight_hh_l0, lp.bias_ih_l0, lp.bias_hh_l0,
                                           lp.weight_ih_l1, lp.weight_hh_l1, lp.bias_ih_l1, lp.bias_hh_l1),
                                    (self.output_layer[0].weight, self.output_layer[0].bias,

@@ -289,3 +289,127 @@ def gen_rollout(cond, lstm_params, head, init_in, starts, ends, target_tm, tf_ma
     g_exec = 2.0 * (4 * H * (H + 7) + 4 * H * 2 * H + (H // 2) * H + 3 * (H // 2))
     L_.call('gmt_bf16_gen_rollout_fwd', ctypes.byref(a), L_.stream(), label='bf16_gen_rollout', flops=g_exec * T * B)
     return out
+
+
+def _slab_unperm_cols(g: torch.Tensor, H: int) -> torch.Tensor:
+    out = torch.empty_like(g)
+    out[:, slab_perm(H, g.device)] = g
+    return out
+
+
+class GenRolloutBf16Fn(torch.autograd.Function):
+    """The training rollout at H = 512: g0 [B, 4H] fp32 (condition term incl. layer-0 biases, torch gate order), w_u [4H, 7],
+    w_hh0, w_ih1, w_hh1 [4H, H], bias1 [4H], head (W1 [H/2, H], b1, W2 [3, H/2], b2), init_in [3] -> out [T, B, 3] fp32.
+    Forward keeps every step's operands and state (gmt_bf16_gen_rollout_fwd, training form), backward is the three-launch
+    BPTT sweep (gmt_bf16_gen_rollout_bwd) followed by the weight-gradient GEMMs over all T*B row-steps."""
+
+    @staticmethod
+    def forward(ctx, g0, w_u, w_hh0, w_ih1, w_hh1, bias1, wh1, bh1, wh2, bh2, init_in, starts, ends, target_tm, tf_list, T):
+        from ._lib import GenBf16Args
+        import ctypes
+        B = g0.shape[0]
+        H = w_hh0.shape[1]
+        if H != 512 or B % ROW_TILE:
+            raise L_.GmtError(f'bf16 generator rollout: H={H} must be 512 and B={B} a multiple of {ROW_TILE}')
+        dev = g0.device
+        XW = 768
+        p = slab_perm(H, dev)
+        with torch.no_grad():
+            w0 = torch.zeros(4 * H, H + 64, device=dev, dtype=torch.float32)
+            w0[:, :H] = w_hh0[p]
+            w0[:, H:H + 7] = w_u[p]
+            w0[:, H + 7:H + 14] = w_u[p]
+            w0 = w0.to(BF16)
+            w1 = torch.cat([w_ih1[p], w_hh1[p]], 1).to(BF16).contiguous()
+            bias1_s = bias1[p].float().contiguous()
+            wh1_b = wh1.to(BF16).contiguous()
+            cond_pre = g0[:, p].to(BF16).contiguous()
+            x0 = torch.zeros(T + 1, B, XW, device=dev, dtype=BF16)
+            rem = ends - starts
+            u0 = torch.cat([init_in.reshape(1, 3).expand(B, 3), rem, torch.sqrt((rem ** 2).sum(-1, keepdim=True) + 1e-8),
+                            torch.atan2(rem[:, 1:2], rem[:, 0:1])], 1).float()
+            u_hi = u0.to(BF16)
+            x0[0, :, H:H + 7] = u_hi
+            x0[0, :, H + 7:H + 14] = (u0 - u_hi.float()).to(BF16)
+            x1 = torch.zeros(T + 1, B, 2 * H, device=dev, dtype=BF16)
+            c0 = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)
+            c1 = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)
+            gates0 = torch.empty(T, B, 4 * H, device=dev, dtype=BF16)
+            gates1 = torch.empty(T, B, 4 * H, device=dev, dtype=BF16)
+            y_all = torch.empty(T, B, H // 2, device=dev, dtype=BF16)
+            oraw = torch.empty(T, B, device=dev, dtype=torch.float32)
+            pos = torch.stack([starts, starts], 0).float().contiguous()
+            out = torch.empty(T, B, 3, device=dev, dtype=torch.float32)
+            tf_dev = None
+            if tf_list is not None and any(tf_list):
+                tf_dev = torch.tensor([1 if b else 0 for b in tf_list], dtype=torch.uint8).to(dev)
+            wh2_c, bh1_c, bh2_c = wh2.detach().float().contiguous(), bh1.detach().float().contiguous(), bh2.detach().float().contiguous()
+            ends_c = ends.float().contiguous()
+            tgt = None if target_tm is None else target_tm.float().contiguous()
+            a = GenBf16Args()
+            (a.cond_pre, a.w0, a.w1, a.bias1, a.wh1, a.bh1, a.wh2, a.bh2, a.ends, a.target, a.tf_mask) = [
+                L_.ptr(t) for t in (cond_pre, w0, w1, bias1_s, wh1_b, bh1_c, wh2_c, bh2_c, ends_c, tgt, tf_dev)]
+            a.out_seq, a.x0, a.x1, a.c0, a.c1, a.pos = (L_.ptr(t) for t in (out, x0, x1, c0, c1, pos))
+            a.gates0, a.gates1, a.y_all, a.oraw_all = (L_.ptr(t) for t in (gates0, gates1, y_all, oraw))
+            a.T, a.B, a.H = T, B, H
+            g_exec = 2.0 * (4 * H * (H + 7) + 4 * H * 2 * H + (H // 2) * H + 3 * (H // 2))
+            L_.call('gmt_bf16_gen_rollout_fwd', ctypes.byref(a), L_.stream(), label='bf16_gen_rollout_train', flops=g_exec * T * B)
+        ctx.save_for_backward(w_u, w_hh0, w_ih1, w_hh1, wh1, wh2)
+        ctx.bufs = (x0, x1, c0, c1, gates0, gates1, y_all, oraw)
+        ctx.cfg = (T, B, H, [bool(b) for b in tf_list] if tf_list is not None else [False] * T)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        from ._lib import GenBf16BwdArgs
+        import ctypes
+        if ctx.bufs is None:
+            raise L_.GmtError('bf16 generator rollout: backward called twice (the saved gate buffers were consumed in place)')
+        w_u, w_hh0, w_ih1, w_hh1, wh1, wh2 = ctx.saved_tensors
+        x0, x1, c0, c1, gates0, gates1, y_all, oraw = ctx.bufs
+        ctx.bufs = None
+        T, B, H, tf = ctx.cfg
+        dev = d_out.device
+        p = slab_perm(H, dev)
+        HH = H // 2
+        w1T = wh1.detach().t().to(BF16).contiguous()                                   # [H, HH]
+        whh1T = w_hh1.detach()[p].t().to(BF16).contiguous()                            # [H, 4H]
+        wih1T = w_ih1.detach()[p].t().to(BF16).contiguous()
+        whh0T = w_hh0.detach()[p].t().to(BF16).contiguous()
+        wu8 = torch.zeros(4 * H, 8, device=dev, dtype=BF16)
+        wu8[:, :7] = w_u.detach()[p]
+        wh2_c = wh2.detach().float().contiguous()
+        dypre = torch.empty(T, B, HH, device=dev, dtype=BF16)
+        d_o = torch.empty(T, B, 3, device=dev, dtype=torch.float32)
+        d_in0 = torch.empty(B, 3, device=dev, dtype=torch.float32)
+        dc0 = torch.empty(B, H, device=dev, dtype=torch.float32)
+        dc1 = torch.empty(B, H, device=dev, dtype=torch.float32)
+        pc = torch.zeros(B, 2, device=dev, dtype=torch.float32)
+        tf_host = (ctypes.c_ubyte * T)(*[1 if b else 0 for b in tf])
+        d_out = d_out.contiguous().float()
+        a = GenBf16BwdArgs()
+        (a.gates0, a.gates1, a.c0, a.c1, a.x0, a.y_all, a.oraw_all, a.d_out, a.w1T, a.whh1T, a.wih1T, a.whh0T, a.w_u, a.wh2,
+         a.dypre_all, a.d_o, a.d_in0, a.dc0, a.dc1, a.p_carry) = [L_.ptr(t) for t in (
+             gates0, gates1, c0, c1, x0, y_all, oraw, d_out, w1T, whh1T, wih1T, whh0T, wu8, wh2_c, dypre, d_o, d_in0, dc0, dc1, pc)]
+        a.tf_mask_host = ctypes.cast(tf_host, ctypes.c_void_p)
+        a.T, a.B, a.H = T, B, H
+        g_exec = 2.0 * (4 * H * (H + 7) + 4 * H * 2 * H + (H // 2) * H + 3 * (H // 2))
+        L_.call('gmt_bf16_gen_rollout_bwd', ctypes.byref(a), L_.stream(), label='bf16_gen_bptt', flops=g_exec * T * B)
+        M = T * B
+        dA0, dA1 = gates0.view(M, 4 * H), gates1.view(M, 4 * H)
+        gw0 = wgrad_tn(dA0, x0[:T].view(M, x0.shape[2]), label='bf16_gen_wgrad0')      # [4H, 768]
+        gw1 = wgrad_tn(dA1, x1[:T].view(M, 2 * H), label='bf16_gen_wgrad1')            # [4H, 2H]
+        d_w_hh0 = slab_unperm_rows(gw0[:, :H].contiguous(), H)
+        d_w_u = slab_unperm_rows((gw0[:, H:H + 7] + gw0[:, H + 7:H + 14]).contiguous(), H)
+        d_w_ih1 = slab_unperm_rows(gw1[:, :H].contiguous(), H)
+        d_w_hh1 = slab_unperm_rows(gw1[:, H:].contiguous(), H)
+        d_bias1 = slab_unperm_rows(dA1.sum(0, dtype=torch.float32), H)
+        d_g0 = _slab_unperm_cols(gates0.sum(0, dtype=torch.float32), H)
+        h1_all = x1[1:].view(M, 2 * H)[:, H:]                                          # h1_t, row stride 2H
+        d_wh1 = wgrad_tn(dypre.view(M, HH), h1_all, label='bf16_gen_wgrad_head')       # [HH, H]
+        d_bh1 = dypre.view(M, HH).sum(0, dtype=torch.float32)
+        d_wh2 = d_o.view(M, 3).t() @ y_all.view(M, HH).float()
+        d_bh2 = d_o.view(M, 3).sum(0)
+        return (d_g0, d_w_u, d_w_hh0, d_w_ih1, d_w_hh1, d_bias1, d_wh1, d_bh1, d_wh2, d_bh2, d_in0.sum(0),
+                None, None, None, None, None)

@@ -383,9 +383,38 @@ typedef struct gmt_bf16_gen_args {
     const unsigned char* tf_mask; /* [T] (device) or NULL: 1 = step t+1 is fed the target of step t (RG.py:588-595) */
     float* out_seq;               /* [T][B][3] (dx, dy, dt) */
     void* x0; void* x1; float* c0; float* c1; float* pos;
+    /* training rollout (all four given, else all NULL): every step keeps its state for the BPTT sweep - x0 is then
+     * [T+1][B][GMT_BF16_GEN_X0_TRAIN_WIDTH] (slot t = the operand of step t; the extra width makes it a weight-gradient tile
+     * multiple), x1 [T+1][B][2H], c0 / c1 [T+1][B][H] (slot t = state BEFORE step t; slots 0 caller-zeroed), and */
+    void* gates0; void* gates1;   /* [T][B][4H] bf16: activated i,f,g,o of layer 0 / 1 (slab order) */
+    void* y_all;                  /* [T][B][H/2] bf16: head activation after LeakyReLU */
+    float* oraw_all;              /* [T][B]: pre-softplus dt logit */
     int T, B, H;
 } gmt_bf16_gen_args;
+#define GMT_BF16_GEN_X0_TRAIN_WIDTH 768
 int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* args, hipStream_t stream);
+
+/* BPTT of the training rollout above (autograd over RG.py:559-595): three launches per timestep in reverse order.  gates0 /
+ * gates1 are overwritten with d(pre-activation) of layer 0 / 1; the caller contracts them (and dypre_all, d_o) with the saved
+ * operands x0 / x1 / y_all for the weight gradients (gmt_bf16_wgrad_tn).  Transposed weights, bf16, K-contiguous, 4H axis in
+ * slab order: w1T [H][H/2] = output_layer.0.weight^T, whh1T / wih1T / whh0T [H][4H], w_u [4H][8] (7 input columns + a zero).
+ * tf_mask_host: the T teacher-forcing flags as a HOST array (they steer pointer choices).  Scratch, no initialisation needed:
+ * dc0 / dc1 [B][H] fp32, p_carry [B][2] fp32. */
+typedef struct gmt_bf16_gen_bwd_args {
+    void* gates0; void* gates1;
+    const float* c0; const float* c1;     /* [T+1][B][H] from the forward launch */
+    const void* x0;                       /* [T+1][B][GMT_BF16_GEN_X0_TRAIN_WIDTH] from the forward launch */
+    const void* y_all; const float* oraw_all;
+    const float* d_out;                   /* [T][B][3] gradient of out_seq */
+    const void* w1T; const void* whh1T; const void* wih1T; const void* whh0T; const void* w_u; const float* wh2;
+    void* dypre_all;                      /* [T][B][H/2] bf16 out: gradient of the head's pre-activation */
+    float* d_o;                           /* [T][B][3] out: gradient of the head's raw output */
+    float* d_in0;                         /* [B][3] out: gradient of the initial input, per row */
+    float* dc0; float* dc1; float* p_carry;
+    const unsigned char* tf_mask_host;
+    int T, B, H;
+} gmt_bf16_gen_bwd_args;
+int gmt_bf16_gen_rollout_bwd(const gmt_bf16_gen_bwd_args* args, hipStream_t stream);
 
 #ifdef __cplusplus
 }
