@@ -80,6 +80,8 @@ _SIGS = {
     'gmt_bf16_lstm_layer_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.c_uint, c_p],
     'gmt_bf16_lstm_layer_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, ctypes.c_uint, c_p],
     'gmt_bf16_wgrad_tn': [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, c_p],
+    'gmt_bf16_lstm_layer_bwd_gp': [c_p] * 11 + [c_i] * 4 + [c_p],
+    'gmt_bf16_lstm_layer_bwd2': [c_p] * 11 + [c_i] * 4 + [c_p],
     'gmt_dx_gemm_resident': [c_i, c_i],
     'gmt_dx_gemm': [c_p, c_p, c_p, c_p, c_f, c_ll, c_i, c_i, c_i, c_p],
     'gmt_traj_from_seq': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],

@@ -283,6 +283,201 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Gradient penalty (compute_gradient_penalty, RG.py:790-842): torch.autograd.grad(..., create_graph=True) differentiates
+// THROUGH the critic's backward pass.  Two more step kernels, for full-length batches (the penalty runs on ceil(0.25 B) rows
+// every 4th D step - 0.4 of 55 GFLOP per trained trajectory - so they trade the LDS-staged epilogues for plain accesses):
+//   lstm_step_bwd_gp_kernel  the backward step, out of place, that also keeps the per-step totals dct / dht (the second-order
+//                            sweep needs them) and/or takes the adjoints of the saved gates / cell states as extra inputs;
+//   lstm_step_bwd2_kernel    the second-order sweep.  The first backward sweep B maps (dY, dh_final; i,f,g,o,c; W) -> dX and is
+//                            linear in dY, so its adjoint is a forward-in-time recurrence of the forward layer's shape,
+//                            ahat_t = xhat_t W_ih^T + hhat_{t-1} W_hh^T (the xhat term hoisted into a GEMM), followed by the
+//                            element-wise second-derivative block (same formulas as csrc/lstm_gp.hip).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS, 2)
+void lstm_step_bwd_gp_kernel(const __bf16* __restrict__ G, __bf16* __restrict__ dA, const float* __restrict__ Call,
+                             const __bf16* __restrict__ dHout, const float* __restrict__ dh_fin,
+                             const float* __restrict__ gg_in, const float* __restrict__ gc_in,
+                             float* __restrict__ dct_all, float* __restrict__ dht_all, float* __restrict__ dc_carry,
+                             const __bf16* __restrict__ WhhT, int L, int B, int H, int ndir, int step, int n_mt, int n_pt)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using T = Tile<2, 2>;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int d, pt, mt;
+    patch_of_block(blockIdx.x, gridDim.x, n_mt, n_pt, d, pt, mt);
+    const int t = d == 0 ? L - 1 - step : step;
+    const int tnext = d == 0 ? t + 1 : t - 1;
+    const int tprev = d == 0 ? t - 1 : t + 1;
+    const bool has_next = step > 0, has_prev = step < L - 1;
+    const long long ldg = (long long)ndir * 4 * H, ldh = (long long)ndir * H;
+    const long long row0 = (long long)mt * T::TQ;
+    f32x16 acc[2][2];
+    zero_acc<2, 2>(acc);
+    mainloop<2, 2>(WhhT + ((long long)d * H + (long long)pt * T::TP) * 4 * H, 4LL * H,
+                   dA + ((long long)tnext * B + row0) * ldg + (long long)d * 4 * H, ldg, has_next ? 4 * H / BK : 0, lds, acc, wave, lane);
+    const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long long b = row0 + wq * 64 + j * 32 + lo;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int un = pt * 128 + wp * 64 + i * 32 + 8 * g4 + 4 * hi;       // unit within the direction
+                const long long go = ((long long)t * B + b) * ldg + (long long)d * 4 * H + (un / 32) * 128 + (un % 32);
+                const long long so = ((long long)t * B + b) * ldh + (long long)d * H + un;
+                const long long sp = ((long long)tprev * B + b) * ldh + (long long)d * H + un;
+                const long long co = ((long long)d * B + b) * H + un;
+                float dh[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dh[e] = acc[i][j][4 * g4 + e];
+                if (dHout) {
+                    const bf16x4 v = *reinterpret_cast<const bf16x4*>(dHout + so);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dh[e] += (float)v[e];
+                }
+                if (step == 0) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(dh_fin + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dh[e] += v[e];
+                }
+                f32x4 dc = {0.f, 0.f, 0.f, 0.f};
+                if (has_next) dc = *reinterpret_cast<const f32x4*>(dc_carry + co);
+                if (gc_in) {                                     // adjoint of the saved c_t (second-order pass)
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(gc_in + so);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dc[e] += v[e];
+                }
+                bf16x4 gt[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gt[g] = *reinterpret_cast<const bf16x4*>(G + go + g * 32);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(Call + so);
+                f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+                if (has_prev) cp = *reinterpret_cast<const f32x4*>(Call + sp);
+                f32x4 xg[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                if (gg_in) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xg[g] = *reinterpret_cast<const f32x4*>(gg_in + go + g * 32);
+                }
+                float da[4][4];
+                f32x4 dcn, dctv, dhtv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gi = (float)gt[0][e], gf = (float)gt[1][e], gg = (float)gt[2][e], gov = (float)gt[3][e];
+                    const float tc = gmt_tanh(c[e]);
+                    const float dct = dc[e] + dh[e] * gov * (1.f - tc * tc);
+                    da[0][e] = (dct * gg + xg[0][e]) * gi * (1.f - gi);
+                    da[1][e] = (dct * cp[e] + xg[1][e]) * gf * (1.f - gf);
+                    da[2][e] = (dct * gi + xg[2][e]) * (1.f - gg * gg);
+                    da[3][e] = (dh[e] * tc + xg[3][e]) * gov * (1.f - gov);
+                    dcn[e] = dct * gf;
+                    dctv[e] = dct; dhtv[e] = dh[e];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<bf16x4*>(dA + go + g * 32) = pack4(da[g][0], da[g][1], da[g][2], da[g][3]);
+                *reinterpret_cast<f32x4*>(dc_carry + co) = dcn;
+                if (dct_all) {
+                    *reinterpret_cast<f32x4*>(dct_all + so) = dctv;
+                    *reinterpret_cast<f32x4*>(dht_all + so) = dhtv;
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS, 2)
+void lstm_step_bwd2_kernel(const __bf16* __restrict__ PH, const __bf16* __restrict__ G, const float* __restrict__ Call,
+                           const float* __restrict__ dct_all, const float* __restrict__ dht_all,
+                           __bf16* __restrict__ hhat_all, float* __restrict__ hhat_fin, float* __restrict__ gg_out,
+                           float* __restrict__ gc_out, float* __restrict__ chat_carry, const __bf16* __restrict__ Whh,
+                           int L, int B, int H, int ndir, int step, int n_mt, int n_pt)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int d, pt, mt;
+    patch_of_block(blockIdx.x, gridDim.x, n_mt, n_pt, d, pt, mt);
+    // the adjoint sweep runs in the FORWARD order of the direction: its step s is the first backward sweep's step L-1-s
+    const int t = d == 0 ? step : L - 1 - step;
+    const int tprev = d == 0 ? t - 1 : t + 1;                  // previous step of this sweep = the forward pass's predecessor
+    const bool has_prev = step > 0;
+    const long long ldg = (long long)ndir * 4 * H, ldh = (long long)ndir * H;
+    const long long row0 = (long long)mt * FWD_TQ;
+    f32x16 acc[4][2];
+    zero_acc<4, 2>(acc);
+    mainloop32<4, 2>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H,
+                     hhat_all + ((long long)tprev * B + row0) * ldh + (long long)d * H, ldh, has_prev ? H / 32 : 0, lds, acc, wave, lane);
+    const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long long b = row0 + wq * 64 + j * 32 + lo;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int un = pt * 64 + wp * 32 + 8 * g4 + 4 * hi;
+            const long long go = ((long long)t * B + b) * ldg + (long long)d * 4 * H + (un / 32) * 128 + (un % 32);
+            const long long so = ((long long)t * B + b) * ldh + (long long)d * H + un;
+            const long long sp = ((long long)tprev * B + b) * ldh + (long long)d * H + un;
+            const long long co = ((long long)d * B + b) * H + un;
+            bf16x4 gt[4], ph[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                gt[g] = *reinterpret_cast<const bf16x4*>(G + go + g * 32);
+                ph[g] = *reinterpret_cast<const bf16x4*>(PH + go + g * 32);
+            }
+            const f32x4 cn = *reinterpret_cast<const f32x4*>(Call + so);
+            f32x4 cpv = {0.f, 0.f, 0.f, 0.f}, chp = {0.f, 0.f, 0.f, 0.f};
+            if (has_prev) {
+                cpv = *reinterpret_cast<const f32x4*>(Call + sp);
+                chp = *reinterpret_cast<const f32x4*>(chat_carry + co);
+            }
+            const f32x4 dctv = *reinterpret_cast<const f32x4*>(dct_all + so);
+            const f32x4 dhtv = *reinterpret_cast<const f32x4*>(dht_all + so);
+            f32x4 ogi, ogf, ogg, ogo, ogc, hnew, chn, gcp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e;
+                const float ig = (float)gt[0][e], fg = (float)gt[1][e], gg = (float)gt[2][e], og = (float)gt[3][e];
+                const float cp = cpv[e], dct = dctv[e], dht = dhtv[e];
+                const float tc = gmt_tanh(cn[e]);
+                const float omt = 1.f - tc * tc;
+                const float di = dct * gg, dg = dct * ig, df = dct * cp, dov = dht * tc;
+                const float a_i = acc[0][j][r] + (float)ph[0][e], a_f = acc[1][j][r] + (float)ph[1][e];
+                const float a_g = acc[2][j][r] + (float)ph[2][e], a_o = acc[3][j][r] + (float)ph[3][e];
+                const float adi = a_i * ig * (1.f - ig);
+                const float adf = a_f * fg * (1.f - fg);
+                const float adg = a_g * (1.f - gg * gg);
+                const float ado = a_o * og * (1.f - og);
+                const float adct = adi * gg + adg * ig + adf * cp + chp[e] * fg;
+                ogi[e] = a_i * di * (1.f - 2.f * ig) + adg * dct;
+                ogf[e] = a_f * df * (1.f - 2.f * fg) + chp[e] * dct;
+                ogg[e] = a_g * dg * (-2.f * gg) + adi * dct;
+                ogo[e] = a_o * dov * (1.f - 2.f * og) + adct * dht * omt;
+                const float atc = adct * dht * og * (-2.f * tc) + ado * dht;
+                ogc[e] = atc * omt;
+                hnew[e] = adct * og * omt + ado * tc;
+                chn[e] = adct;
+                gcp[e] = adf * dct;                              // what c_{t-1} receives through the forget-gate adjoint
+            }
+            *reinterpret_cast<f32x4*>(gg_out + go + 0 * 32) = ogi;
+            *reinterpret_cast<f32x4*>(gg_out + go + 1 * 32) = ogf;
+            *reinterpret_cast<f32x4*>(gg_out + go + 2 * 32) = ogg;
+            *reinterpret_cast<f32x4*>(gg_out + go + 3 * 32) = ogo;
+            *reinterpret_cast<f32x4*>(gc_out + so) = ogc;
+            if (has_prev) {                                      // the previous launch wrote its own part of g_c[t_prev]
+                f32x4 v = *reinterpret_cast<const f32x4*>(gc_out + sp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += gcp[e];
+                *reinterpret_cast<f32x4*>(gc_out + sp) = v;
+            }
+            *reinterpret_cast<f32x4*>(chat_carry + co) = chn;
+            *reinterpret_cast<bf16x4*>(hhat_all + so) = pack4(hnew[0], hnew[1], hnew[2], hnew[3]);
+            if (step == L - 1) *reinterpret_cast<f32x4*>(hhat_fin + co) = hnew;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, void* h_drop, const void* w_hh,
@@ -321,6 +516,41 @@ extern "C" int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const vo
         hipLaunchKernelGGL(k, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), T::LDS_BYTES, stream, (__bf16*)gates, c_all,
                            (const __bf16*)dh_out, dh_fin, dc_carry, dh_carry, (const __bf16*)w_hhT, lengths, L, B, H, ndir, step,
                            n_mt, n_pt, drop_p, drop_seed);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+extern "C" int gmt_bf16_lstm_layer_bwd_gp(const void* gates, void* dA, const float* c_all, const void* dh_out, const float* dh_fin,
+                                          const float* gg_in, const float* gc_in, float* dct_all, float* dht_all,
+                                          float* dc_carry, const void* w_hhT, int L, int B, int H, int ndir, hipStream_t stream)
+{
+    using T = Tile<2, 2>;
+    GMT_CHECK_ARG(gates && dA && c_all && dh_fin && dc_carry && w_hhT && L >= 1 && (ndir == 1 || ndir == 2));
+    GMT_CHECK_ARG(B > 0 && B % 256 == 0 && H > 0 && H % T::TP == 0 && (dct_all == nullptr) == (dht_all == nullptr));
+    const int n_mt = B / T::TQ, n_pt = H / T::TP;
+    if (hipFuncSetAttribute((const void*)lstm_step_bwd_gp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess)
+        return GMT_ERR_HIP;
+    for (int step = 0; step < L; ++step)
+        hipLaunchKernelGGL(lstm_step_bwd_gp_kernel, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), T::LDS_BYTES, stream,
+                           (const __bf16*)gates, (__bf16*)dA, c_all, (const __bf16*)dh_out, dh_fin, gg_in, gc_in, dct_all, dht_all,
+                           dc_carry, (const __bf16*)w_hhT, L, B, H, ndir, step, n_mt, n_pt);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+extern "C" int gmt_bf16_lstm_layer_bwd2(const void* pre_hat, const void* gates, const float* c_all, const float* dct_all,
+                                        const float* dht_all, void* hhat_all, float* hhat_fin, float* g_gates, float* g_c,
+                                        float* chat_carry, const void* w_hh, int L, int B, int H, int ndir, hipStream_t stream)
+{
+    GMT_CHECK_ARG(pre_hat && gates && c_all && dct_all && dht_all && hhat_all && hhat_fin && g_gates && g_c && chat_carry && w_hh);
+    GMT_CHECK_ARG(L >= 1 && (ndir == 1 || ndir == 2) && B > 0 && B % 256 == 0 && H > 0 && (4 * H) % TP == 0 && H % BK == 0);
+    const int n_mt = B / FWD_TQ, n_pt = 4 * H / TP;
+    if (hipFuncSetAttribute((const void*)lstm_step_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS) != hipSuccess)
+        return GMT_ERR_HIP;
+    for (int step = 0; step < L; ++step)
+        hipLaunchKernelGGL(lstm_step_bwd2_kernel, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), FWD_LDS, stream,
+                           (const __bf16*)pre_hat, (const __bf16*)gates, c_all, dct_all, dht_all, (__bf16*)hhat_all, hhat_fin,
+                           g_gates, g_c, chat_carry, (const __bf16*)w_hh, L, B, H, ndir, step, n_mt, n_pt);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }

@@ -413,3 +413,175 @@ class GenRolloutBf16Fn(torch.autograd.Function):
         d_bh2 = d_o.view(M, 3).sum(0)
         return (d_g0, d_w_u, d_w_hh0, d_w_ih1, d_w_hh1, d_bias1, d_wh1, d_bh1, d_wh2, d_bh2, d_in0.sum(0),
                 None, None, None, None, None)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# gradient penalty at H = 512 (compute_gradient_penalty, RG.py:790-842): the BiLSTM stack as a twice-differentiable op
+# ----------------------------------------------------------------------------------------------------------------------
+class _Saved:
+    """What the stack's forward keeps for its two backward forms (a plain Python holder: not a tensor argument)."""
+    def __init__(self):
+        self.layers, self.dims, self.first = [], None, None
+
+
+class LSTMStackGPFn(torch.autograd.Function):
+    """e [L, B, H] fp32 (the feature encoder's output; full-length rows only), the LSTM parameters -> h_final [B, 2H] fp32.
+    Under create_graph=True (the penalty's autograd.grad w.r.t. the interpolated positions) its backward is the differentiable
+    op LSTMStackBwdGPFn; the penalty's own backward then runs the second-order sweep.  Inter-layer dropout is NOT applied on
+    this pass (the reference draws a fresh mask here too; statistically the penalty is that of the dropout-free critic)."""
+
+    @staticmethod
+    def forward(ctx, e, n_layers, *lw):
+        L, B, H = e.shape
+        nd = 2
+        if B % ROW_TILE or H % 256:
+            raise L_.GmtError(f'bf16 gradient penalty: B={B} must be a multiple of {ROW_TILE}, H={H} of 256')
+        dev = e.device
+        M = L * B
+        hold = _Saved()
+        hold.dims = (L, B, H, nd, int(n_layers))
+        x = e.detach().reshape(M, H).to(BF16).contiguous()
+        for l in range(n_layers):
+            ws = list(lw[4 * nd * l: 4 * nd * (l + 1)])
+            wih, bias, whh, whhT, wihT = lstm_layer_weights(ws, H, nd)
+            G = gemm_nt(x, wih, bias, None, 0, 0.0, label=f'bf16_gp_pre_l{l}')
+            c_all = torch.empty(M, nd * H, device=dev, dtype=torch.float32)
+            h_all = torch.empty(M, nd * H, device=dev, dtype=BF16)
+            L_.call('gmt_bf16_lstm_layer_fwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(h_all), None, L_.ptr(whh), None, 0, L, B, H, nd,
+                    0.0, 0, L_.stream(), label='bf16_gp_lstm_fwd', flops=2.0 * (L - 1) * B * nd * 4 * H * H)
+            hold.layers.append((x, G, c_all, h_all))
+            x = h_all
+        ctx.hold = hold
+        ctx.save_for_backward(e, *lw)
+        ctx.set_materialize_grads(False)
+        return torch.cat([x[(L - 1) * B:, :H], x[:B, H:]], 1).float()
+
+    @staticmethod
+    def backward(ctx, dh_final):
+        e, *lw = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            # first backward under create_graph=True (the penalty's autograd.grad w.r.t. the interpolated positions): only the
+            # input gradient is asked for, and it is produced by a differentiable op
+            de = LSTMStackBwdGPFn.apply(dh_final, e, ctx.hold, *lw)
+            return (de, None) + (None,) * len(lw)
+        # The penalty's own backward reaches this node once more, through the head's double backward (the adjoint of h_final
+        # as a saved activation of the head).  The head is piecewise linear, so that adjoint is identically zero: nothing to add
+        # to what LSTMStackBwdGPFn.backward already returned.  Anything else is not the gradient penalty.
+        hold = ctx.hold
+        hold.layers, hold.first = [], None
+        if dh_final is None or not bool(dh_final.any().item()):
+            return (None, None) + (None,) * len(lw)
+        raise L_.GmtError('LSTMStackGPFn serves the gradient penalty only; the ordinary critic pass is ops_bf16.critic_body')
+
+
+class LSTMStackBwdGPFn(torch.autograd.Function):
+    """The first backward sweep of the stack as a differentiable op: (dh_final, e, parameters) -> de.  Its backward is the
+    second-order pass: per layer the hoisted xhat W_ih^T GEMM + gmt_bf16_lstm_layer_bwd2, the explicit weight terms
+    (da^T xhat, da^T hhat), then an ordinary backward sweep that takes the adjoints of the saved gates / cell states as extra
+    inputs and yields the remaining parameter gradients and the gradient w.r.t. e."""
+
+    @staticmethod
+    def forward(ctx, dh_final, e, hold, *lw):
+        L, B, H, nd, n_layers = hold.dims
+        dev = e.device
+        M = L * B
+        dh_fin = torch.stack([dh_final[:, :H], dh_final[:, H:]], 0).float().contiguous()
+        dcc = torch.empty(nd, B, H, device=dev, dtype=torch.float32)
+        first = []
+        dh_out = None
+        for l in range(n_layers - 1, -1, -1):
+            x, G, c_all, h_all = hold.layers[l]
+            ws = list(lw[4 * nd * l: 4 * nd * (l + 1)])
+            wih, bias, whh, whhT, wihT = lstm_layer_weights(ws, H, nd)
+            da = torch.empty_like(G)
+            dct = torch.empty(M, nd * H, device=dev, dtype=torch.float32)
+            dht = torch.empty(M, nd * H, device=dev, dtype=torch.float32)
+            L_.call('gmt_bf16_lstm_layer_bwd_gp', L_.ptr(G), L_.ptr(da), L_.ptr(c_all), L_.ptr(dh_out), L_.ptr(dh_fin), None, None,
+                    L_.ptr(dct), L_.ptr(dht), L_.ptr(dcc), L_.ptr(whhT), L, B, H, nd, L_.stream(), label='bf16_gp_lstm_bwd',
+                    flops=2.0 * (L - 1) * B * nd * 4 * H * H)
+            first.insert(0, (da, dct, dht))
+            dh_out = gemm_nt(da, wihT, None, None, 0, 0.0, label=f'bf16_gp_dx_l{l}')
+            dh_fin = torch.zeros_like(dh_fin)
+        hold.first = first
+        ctx.hold = hold
+        ctx.save_for_backward(*lw)
+        return dh_out.float().view(L, B, H)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, xhat):
+        lw = ctx.saved_tensors
+        hold = ctx.hold
+        L, B, H, nd, n_layers = hold.dims
+        dev = xhat.device
+        M = L * B
+        p = slab_perm(H, dev)
+        g_lw = [None] * len(lw)
+        xh = xhat.reshape(M, H).to(BF16).contiguous()
+        second = []
+        hhat_fin = None
+        for l in range(n_layers):                      # the adjoint chain runs bottom-up: layer 0's sweep produced de
+            x, G, c_all, h_all = hold.layers[l]
+            da, dct, dht = hold.first[l]
+            ws = list(lw[4 * nd * l: 4 * nd * (l + 1)])
+            wih, bias, whh, whhT, wihT = lstm_layer_weights(ws, H, nd)
+            PH = gemm_nt(xh, wih, None, None, 0, 0.0, label=f'bf16_gp_prehat_l{l}')
+            hhat = torch.empty(M, nd * H, device=dev, dtype=BF16)
+            hhat_fin = torch.empty(nd, B, H, device=dev, dtype=torch.float32)
+            gg = torch.empty(M, nd * 4 * H, device=dev, dtype=torch.float32)
+            gc = torch.empty(M, nd * H, device=dev, dtype=torch.float32)
+            chat = torch.empty(nd, B, H, device=dev, dtype=torch.float32)
+            L_.call('gmt_bf16_lstm_layer_bwd2', L_.ptr(PH), L_.ptr(G), L_.ptr(c_all), L_.ptr(dct), L_.ptr(dht), L_.ptr(hhat),
+                    L_.ptr(hhat_fin), L_.ptr(gg), L_.ptr(gc), L_.ptr(chat), L_.ptr(whh), L, B, H, nd, L_.stream(),
+                    label='bf16_gp_lstm_bwd2', flops=2.0 * (L - 1) * B * nd * 4 * H * H)
+            # explicit weight terms of the first backward sweep: dX = da W_ih, dh_t = dh_out[t] + da_{t+-1} W_hh
+            e_wih = wgrad_tn(da, xh, label='bf16_gp_wgrad_ih2')
+            for d in range(nd):
+                cols = slice(d * 4 * H, (d + 1) * 4 * H)
+                if d == 0:
+                    e_whh = wgrad_tn(da[B:, cols], hhat[:M - B, :H], label='bf16_gp_wgrad_hh2')
+                else:
+                    e_whh = wgrad_tn(da[:M - B, cols], hhat[B:, H:], label='bf16_gp_wgrad_hh2')
+                k = 4 * nd * l + 4 * d
+                g_lw[k] = slab_unperm_rows(e_wih[cols], H)
+                g_lw[k + 1] = slab_unperm_rows(e_whh, H)
+            second.append((gg, gc))
+            xh = hhat
+        hhat_final = torch.cat([hhat_fin[0], hhat_fin[1]], 1)
+        # ordinary backward sweep through the forward pass, fed by the adjoints of its saved activations
+        zero_fin = torch.zeros(nd, B, H, device=dev, dtype=torch.float32)
+        dcc = torch.empty(nd, B, H, device=dev, dtype=torch.float32)
+        dh_out = None
+        g_e = None
+        for l in range(n_layers - 1, -1, -1):
+            x, G, c_all, h_all = hold.layers[l]
+            gg, gc = second[l]
+            ws = list(lw[4 * nd * l: 4 * nd * (l + 1)])
+            wih, bias, whh, whhT, wihT = lstm_layer_weights(ws, H, nd)
+            da2 = torch.empty_like(G)
+            L_.call('gmt_bf16_lstm_layer_bwd_gp', L_.ptr(G), L_.ptr(da2), L_.ptr(c_all), L_.ptr(dh_out), L_.ptr(zero_fin), L_.ptr(gg),
+                    L_.ptr(gc), None, None, L_.ptr(dcc), L_.ptr(whhT), L, B, H, nd, L_.stream(), label='bf16_gp_lstm_bwd_x',
+                    flops=2.0 * (L - 1) * B * nd * 4 * H * H)
+            d_wih = wgrad_tn(da2, x, label='bf16_gp_wgrad_ih')
+            db = da2.sum(0, dtype=torch.float32)
+            for d in range(nd):
+                cols = slice(d * 4 * H, (d + 1) * 4 * H)
+                if d == 0:
+                    d_whh = wgrad_tn(da2[B:, cols], h_all[:M - B, :H], label='bf16_gp_wgrad_hh')
+                else:
+                    d_whh = wgrad_tn(da2[:M - B, cols], h_all[B:, H:], label='bf16_gp_wgrad_hh')
+                k = 4 * nd * l + 4 * d
+                g_lw[k] = g_lw[k] + slab_unperm_rows(d_wih[cols], H)
+                g_lw[k + 1] = g_lw[k + 1] + slab_unperm_rows(d_whh, H)
+                g_lw[k + 2] = slab_unperm_rows(db[cols], H)
+                g_lw[k + 3] = g_lw[k + 2]
+            dx = gemm_nt(da2, wihT, None, None, 0, 0.0, label=f'bf16_gp_dx2_l{l}')
+            if l > 0:
+                dh_out = dx
+            else:
+                g_e = dx.float().view(L, B, H)
+        return (hhat_final, g_e, None, *g_lw)
+
+
+def lstm_stack_gp(e, n_layers, lstm_weights):
+    return LSTMStackGPFn.apply(e, n_layers, *lstm_weights)

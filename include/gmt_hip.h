@@ -361,6 +361,21 @@ int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const void* dh_out,
                             float* dh_carry, const void* w_hhT, const int* lengths, int ragged, int L, int B, int H,
                             int ndir, float drop_p, unsigned int drop_seed, hipStream_t stream);
 
+/* Gradient penalty at this width (compute_gradient_penalty, RG.py:790-842; full-length batches only).
+ * gmt_bf16_lstm_layer_bwd_gp: the backward sweep out of place (gates is kept, dA [L][B][ndir*4H] bf16 is written), which can also
+ * keep the per-step totals dct_all / dht_all [L][B][ndir*H] fp32 the second-order sweep needs (first backward under
+ * create_graph=True), and take the adjoints of the saved activations as extra inputs (gg_in [L][B][ndir*4H], gc_in
+ * [L][B][ndir*H], fp32; the pass after the second-order sweep).
+ * gmt_bf16_lstm_layer_bwd2: the second-order sweep.  pre_hat [L][B][ndir*4H] bf16 = xhat W_ih^T (xhat = adjoint of the sweep's
+ * dX); outputs hhat_all [L][B][ndir*H] bf16 (adjoint of dh_out = the xhat of the layer above), hhat_fin [ndir][B][H] fp32 (adjoint
+ * of dh_fin), g_gates / g_c (adjoints of the saved activated gates / cell states, fp32).  chat_carry [ndir][B][H] fp32: scratch. */
+int gmt_bf16_lstm_layer_bwd_gp(const void* gates, void* dA, const float* c_all, const void* dh_out, const float* dh_fin,
+                               const float* gg_in, const float* gc_in, float* dct_all, float* dht_all, float* dc_carry,
+                               const void* w_hhT, int L, int B, int H, int ndir, hipStream_t stream);
+int gmt_bf16_lstm_layer_bwd2(const void* pre_hat, const void* gates, const float* c_all, const float* dct_all,
+                             const float* dht_all, void* hhat_all, float* hhat_fin, float* g_gates, float* g_c,
+                             float* chat_carry, const void* w_hh, int L, int B, int H, int ndir, hipStream_t stream);
+
 /* Weight gradients of the bf16 path: slabs[s][n][i] = sum over the s-th of n_slabs row ranges of dA[r][n] * X[r][i]
  * (autograd's dW = dA^T X for the LSTM and encoder weights; the caller sums the n_slabs fp32 partial results - deterministic).
  * dA [M][lda], X [M][ldx] bf16; M % 64 == 0, N % 256 == 0, I % 256 == 0. */

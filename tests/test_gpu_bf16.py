@@ -302,3 +302,115 @@ def test_bf16_generator_refuses_what_is_not_built():
     s = torch.rand(4, 2, device=DEV)
     with pytest.raises(NotImplementedError):
         G(s, s + 0.1, torch.randn(4, cfg.latent_dim, device=DEV), torch.zeros(4, 8, 3, device=DEV))
+
+
+def _gp_case(Hd, Bs, T, seed, dt_scale):
+    """compute_gradient_penalty (RG.py:790-842) through the bf16 critic: value and the gradient of the penalty w.r.t. every
+    critic parameter (the second-order sweep) against the fp64 oracle."""
+    import generative_mouse_trajectories_amd as gmt
+    over = dict(latent_dim=8, generator_hidden_dim=32, discriminator_hidden_dim=Hd)
+    cfg = gmt.Config()
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    cfg.lstm_dropout = cfg.head_dropout = 0.0
+    cfg.compute_dtype = 'bf16'
+    pd, bd = PG.make_discriminator_params(O.OracleConfig(**over), seed)
+    D = gmt.Discriminator(cfg)
+    sd = {k: torch.from_numpy(v) for k, v in pd.items()}
+    sd.update({k: torch.from_numpy(v) for k, v in bd.items()})
+    D.load_state_dict(sd, strict=True)
+    D = D.to(DEV).train()
+    br = H.batch_t(Bs, T, seed + 1, [T] * Bs, torch.float32)
+    bf = H.batch_t(Bs, T, seed + 2, [T] * Bs, torch.float32)
+    rt = gmt.trajectory_to_absolute(br['starts'], br['sequences'][:, :, :2])
+    ft = gmt.trajectory_to_absolute(bf['starts'], bf['sequences'][:, :, :2])
+    rd = torch.nn.functional.pad(br['sequences'][:, :, 2], (1, 0), value=0.001) * dt_scale
+    fd = torch.nn.functional.pad(bf['sequences'][:, :, 2], (1, 0), value=0.001) * dt_scale
+    lens = torch.full((Bs,), T + 1)
+    alpha = torch.rand(Bs, 1, 1, generator=torch.Generator().manual_seed(seed + 3))
+    D.zero_grad()
+    gp = gmt.compute_gradient_penalty(D, rt.to(DEV), ft.to(DEV), rd.to(DEV), fd.to(DEV), lens.to(DEV), DEV, alpha=alpha.to(DEV))
+    gp.backward()
+    Pd = {k: H.t(v, torch.float64).requires_grad_(True) for k, v in pd.items()}
+    Bd = {k: H.t(v, torch.float64) for k, v in bd.items()}
+    ref = O.gradient_penalty(Pd, Bd, rt.double(), ft.double(), rd.double(), fd.double(), lens, alpha.double())
+    keys = list(Pd.keys())
+    g64 = dict(zip(keys, torch.autograd.grad(ref, [Pd[k] for k in keys], allow_unused=True)))     # (the last bias does not reach the penalty)
+    err, cosines = {}, {}
+    for k, p in D.named_parameters():
+        if g64[k] is None or p.grad is None or float(g64[k].norm()) == 0.0:
+            continue
+        a, c = g64[k].flatten(), p.grad.detach().cpu().double().flatten()
+        err[k] = float((c - a).norm() / a.norm())
+        cosines[k] = float(a @ c / (a.norm() * c.norm()))
+    e_v = abs(gp.item() - ref.item()) / abs(ref.item())
+    kmax = max(err, key=lambda k: err[k])
+    print(f'bf16 gradient penalty H={Hd} B={Bs} T={T}: value {gp.item():.4f} vs {ref.item():.4f} ({e_v:.1e}); parameter gradients: '
+          f'worst relative L2 error {err[kmax]:.1e} ({kmax}), lowest cosine {min(cosines.values()):.4f}')
+    return e_v, err, cosines
+
+
+def test_bf16_gradient_penalty_vs_fp64_oracle():
+    """Value and second-order parameter gradients of compute_gradient_penalty through the bf16 critic (H = 256, interpolates of
+    two unrelated batches).  The penalty squares a gradient NORM, which bf16 noise inflates (|g + n|^2 = |g|^2 + |n|^2): the
+    value sits 5-10 % above the oracle's and every parameter gradient is longer by about as much, while its DIRECTION agrees to
+    cosine > 0.995.  Bars: value 1.5e-1, relative L2 error 1.5e-1, cosine 0.99.  (The step kernels themselves are compared with
+    the tested backward kernel and with the fp32 second-order kernel in the next test.)"""
+    e_v, err, cosines = _gp_case(256, 64, 16, 131, 50.0)
+    assert e_v <= 1.5e-1
+    for k in err:
+        assert err[k] <= 1.5e-1 and cosines[k] >= 0.99, (k, err[k], cosines[k])
+
+
+def test_bf16_gradient_penalty_step_kernels():
+    """gmt_bf16_lstm_layer_bwd_gp is the backward sweep out of place: bit-identical d(pre-activation) to gmt_bf16_lstm_layer_bwd.
+    gmt_bf16_lstm_layer_bwd2 against the fp32 path's gmt_lstm_layer_bwd2 on the same saved activations (H = 256, I = 256)."""
+    from generative_mouse_trajectories_amd import ops, ops_bf16 as OB
+    L_ = _L()
+    g = torch.Generator(device='cuda').manual_seed(7)
+    L, B, Hd = 6, 256, 256
+    perm = OB.slab_perm(Hd, DEV)
+    pre = torch.randn(L, B, 2, 4 * Hd, device=DEV, generator=g).to(BF).float()
+    whh = (torch.randn(2, 4 * Hd, Hd, device=DEV, generator=g) / Hd ** 0.5).to(BF).float()
+    wih = (torch.randn(2, 4 * Hd, Hd, device=DEV, generator=g) / Hd ** 0.5).to(BF).float()
+    lengths = torch.full((B,), L, device=DEV, dtype=torch.int32)
+    G = pre[:, :, :, perm].reshape(L, B, 8 * Hd).to(BF).contiguous()
+    c_all = torch.empty(L, B, 2 * Hd, device=DEV); h_all = torch.empty(L, B, 2 * Hd, device=DEV, dtype=BF)
+    wpk = whh[:, perm, :].to(BF).contiguous(); wT = whh[:, perm, :].transpose(1, 2).to(BF).contiguous()
+    L_.call('gmt_bf16_lstm_layer_fwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(h_all), None, L_.ptr(wpk), None, 0, L, B, Hd, 2, 0.0, 0, L_.stream())
+    gfin = torch.randn(2, B, Hd, device=DEV, generator=g)
+    gh = (torch.randn(L, B, 2 * Hd, device=DEV, generator=g) * 0.1).to(BF)
+    G1 = G.clone(); dcc = torch.empty(2, B, Hd, device=DEV)
+    L_.call('gmt_bf16_lstm_layer_bwd', L_.ptr(G1), L_.ptr(c_all), L_.ptr(gh), L_.ptr(gfin), L_.ptr(dcc), None, L_.ptr(wT), None, 0,
+            L, B, Hd, 2, 0.0, 0, L_.stream())
+    dA = torch.empty_like(G); dct = torch.empty(L, B, 2 * Hd, device=DEV); dht = torch.empty(L, B, 2 * Hd, device=DEV)
+    L_.call('gmt_bf16_lstm_layer_bwd_gp', L_.ptr(G), L_.ptr(dA), L_.ptr(c_all), L_.ptr(gh), L_.ptr(gfin), None, None, L_.ptr(dct),
+            L_.ptr(dht), L_.ptr(dcc), L_.ptr(wT), L, B, Hd, 2, L_.stream())
+    assert torch.equal(dA, G1)
+
+    def unit_major(Gs):                                   # [L][B][2*4H slab order] -> the fp32 kernels' [2][L][B][4H], column 4 u + gate
+        out = torch.empty(2, L, B, 4 * Hd, device=DEV)
+        Gs = Gs.float().view(L, B, 2, 4 * Hd)
+        u = torch.arange(Hd, device=DEV)
+        for gate in range(4):
+            out[:, :, :, 4 * u + gate] = Gs[:, :, :, (u // 32) * 128 + gate * 32 + (u % 32)].permute(2, 0, 1, 3)
+        return out.contiguous()
+    planes = lambda x: x.view(L, B, 2, Hd).permute(2, 0, 1, 3).contiguous()
+    gates32, c32, dct32, dht32 = unit_major(G), planes(c_all), planes(dct), planes(dht)
+    xhat = torch.randn(L, B, Hd, device=DEV, generator=g).to(BF).float()
+    hhat32 = torch.empty(L, B, 2 * Hd, device=DEV); hfin32 = torch.empty(B, 2 * Hd, device=DEV)
+    gg32 = torch.empty_like(gates32); gc32 = torch.empty_like(c32)
+    w_ih_pk = ops.pack_forward([wih[0].contiguous(), wih[1].contiguous()], Hd, Hd)        # (kept alive until the launch has run)
+    w_hh_pk = ops.pack_forward([whh[0].contiguous(), whh[1].contiguous()], Hd, Hd)
+    xhat = xhat.contiguous()
+    L_.call('gmt_lstm_layer_bwd2', L_.ptr(xhat), L_.ptr(w_ih_pk), L_.ptr(w_hh_pk), L_.ptr(lengths), L_.ptr(gates32), L_.ptr(c32),
+            L_.ptr(dct32), L_.ptr(dht32), L_.ptr(hhat32), L_.ptr(hfin32), L_.ptr(gg32), L_.ptr(gc32), L, B, Hd, Hd, 2, L_.stream())
+    PH = OB.gemm_nt(xhat.view(L * B, Hd).to(BF).contiguous(), torch.cat([wih[0][perm], wih[1][perm]], 0).to(BF).contiguous())
+    hhat = torch.empty(L * B, 2 * Hd, device=DEV, dtype=BF); hfin = torch.empty(2, B, Hd, device=DEV)
+    gg = torch.empty(L * B, 8 * Hd, device=DEV); gc = torch.empty(L * B, 2 * Hd, device=DEV); chat = torch.empty(2, B, Hd, device=DEV)
+    L_.call('gmt_bf16_lstm_layer_bwd2', L_.ptr(PH), L_.ptr(G), L_.ptr(c_all), L_.ptr(dct), L_.ptr(dht), L_.ptr(hhat), L_.ptr(hfin),
+            L_.ptr(gg), L_.ptr(gc), L_.ptr(chat), L_.ptr(wpk), L, B, Hd, 2, L_.stream())
+    H.assert_close(hhat.float().view(L, B, 2 * Hd), hhat32, 1e-2, 'second-order sweep: hhat_all')
+    H.assert_close(torch.cat([hfin[0], hfin[1]], 1), hfin32, 1e-2, 'hhat_final')
+    H.assert_close(unit_major(gg.view(L, B, 8 * Hd)), gg32, 1e-2, 'adjoint of the saved gates')
+    H.assert_close(planes(gc), gc32, 1e-2, 'adjoint of the saved cell states')
