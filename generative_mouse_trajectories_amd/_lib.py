@@ -41,13 +41,14 @@ class GenBwdArgs(ctypes.Structure):
 
 class GenBf16Args(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ('cond_pre', 'w0', 'w1', 'bias1', 'wh1', 'bh1', 'wh2', 'bh2', 'ends', 'target', 'tf_mask',
-                                   'out_seq', 'x0', 'x1', 'c0', 'c1', 'pos', 'gates0', 'gates1', 'y_all', 'oraw_all')] + [('T', c_i), ('B', c_i), ('H', c_i)]
+                                   'out_seq', 'x0', 'x1', 'c0', 'c1', 'pos', 'gates0', 'gates1', 'y_all', 'oraw_all')] \
+        + [('T', c_i), ('B', c_i), ('H', c_i), ('dropout_p', c_f), ('seed', ctypes.c_uint)]
 
 
 class GenBf16BwdArgs(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ('gates0', 'gates1', 'c0', 'c1', 'x0', 'y_all', 'oraw_all', 'd_out', 'w1T', 'whh1T', 'wih1T',
                                    'whh0T', 'w_u', 'wh2', 'dypre_all', 'd_o', 'd_in0', 'dc0', 'dc1', 'p_carry',
-                                   'tf_mask_host')] + [('T', c_i), ('B', c_i), ('H', c_i)]
+                                   'tf_mask_host')] + [('T', c_i), ('B', c_i), ('H', c_i), ('dropout_p', c_f), ('seed', ctypes.c_uint)]
 
 
 class SnFwdLayer(ctypes.Structure):

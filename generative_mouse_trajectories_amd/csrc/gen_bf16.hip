@@ -11,13 +11,15 @@
 // (slots 0-6 u_hi, 7-13 u_lo, both against W_u): they span 1e-3 .. 1e0 and steer the trajectory, 8 bits are not enough.
 // The condition term cond W_cond^T + b is constant over time and computed once by the caller (gmt_bf16_gemm_nt).
 #include "bf16_tile.h"
+#include "lstm_tile.h"      // gmt_keep: the generator's counter-based inter-layer dropout mask, as in the fp32 rollout
 
 namespace {
 
 using namespace gmt_bf16;
 
 constexpr int G_TQ = 128;                                      // rows per workgroup (two workgroups per CU)
-constexpr int G_PRE_OFF = 0, G_C_OFF = 64 * 512, G_H_OFF = G_C_OFF + 64 * 256, G_LDS = G_H_OFF + 64 * 128;   // 56 KiB
+constexpr int G_PRE_OFF = 0, G_C_OFF = 64 * 512, G_H_OFF = G_C_OFF + 64 * 256, G_HD_OFF = G_H_OFF + 64 * 128;
+constexpr int G_LDS = G_HD_OFF + 64 * 128;                     // 64 KiB
 
 // One LSTM layer step over all rows.  X: [B][ldx] bf16 (K = 32 nk32 columns used); W: [4H slab order][32 nk32] bf16.
 // pre: [B][4H] bf16 plane (slab order) or NULL (then bias[4H]); c_prev -> c_out [B][H] fp32; h -> h0 (and h1 if given).
@@ -26,7 +28,7 @@ void gen_cell_kernel(const __bf16* __restrict__ W, const __bf16* __restrict__ X,
                      const __bf16* __restrict__ pre, const float* __restrict__ bias,
                      const float* __restrict__ c_prev, float* __restrict__ c_out,
                      __bf16* __restrict__ h0, long long ldh0, __bf16* __restrict__ h1, long long ldh1,
-                     __bf16* __restrict__ gates_out, int H, int n_mt, int n_pt)
+                     __bf16* __restrict__ gates_out, int H, int n_mt, int n_pt, float drop_p, uint32_t drop_seed, long long drop_row0)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -49,6 +51,10 @@ void gen_cell_kernel(const __bf16* __restrict__ W, const __bf16* __restrict__ X,
     const char* Cp = (const char*)(c_prev + row0 * H + pt * (TP / 4));
     char* Co = (char*)(c_out + row0 * H + pt * (TP / 4));
     char* Go = gates_out ? (char*)(gates_out + row0 * 4 * H + pt * TP) : nullptr;     // training: the activated gates, for BPTT
+    // nn.LSTM's inter-layer dropout (RG.py:451-457): the copy of h that feeds the next layer (h1) goes through the mask
+    // keep(seed, (t*B + row)*H + unit) - ops.dropout_keep_mask(T, B, H, p, seed) replays it; the recurrent copy (h0) does not
+    const uint32_t thresh24 = (uint32_t)(drop_p * 16777216.0f);
+    const float keep_scale = 1.0f / (1.0f - drop_p);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         auto rowmap = [j](int r) { return (r >> 5) * 64 + j * 32 + (r & 31); };
@@ -91,12 +97,18 @@ void gen_cell_kernel(const __bf16* __restrict__ W, const __bf16* __restrict__ X,
             }
             *reinterpret_cast<f32x4*>(lds + G_C_OFF + CI::addr(rl, ucol * 4)) = cn;
             *reinterpret_cast<bf16x4*>(lds + G_H_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
+            if (h1 && thresh24) {
+                const uint32_t idx = (uint32_t)((drop_row0 + row0 + wq * 64 + j * 32 + lo) * H + pt * (TP / 4) + ucol);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hn[e] = gmt_keep(idx + e, drop_seed, thresh24) ? hn[e] * keep_scale : 0.f;
+                *reinterpret_cast<bf16x4*>(lds + G_HD_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
+            }
         }
         __syncthreads();
         CI::copy_out(Co, (long long)H * 4, lds + G_C_OFF, 64, rowmap, wave, lane);
         if (Go) GI::copy_out(Go, 4LL * H * 2, lds + G_PRE_OFF, 64, rowmap, wave, lane);
         HI::copy_out((char*)(h0 + row0 * ldh0 + pt * (TP / 4)), ldh0 * 2, lds + G_H_OFF, 64, rowmap, wave, lane);
-        if (h1) HI::copy_out((char*)(h1 + row0 * ldh1 + pt * (TP / 4)), ldh1 * 2, lds + G_H_OFF, 64, rowmap, wave, lane);
+        if (h1) HI::copy_out((char*)(h1 + row0 * ldh1 + pt * (TP / 4)), ldh1 * 2, lds + (thresh24 ? G_HD_OFF : G_H_OFF), 64, rowmap, wave, lane);
     }
 }
 
@@ -207,7 +219,8 @@ __global__ __launch_bounds__(NTHREADS, 2)
 void gen_bwd_cell_kernel(const __bf16* __restrict__ P1, const __bf16* __restrict__ Q1, long long ldq1, int nk1,
                          const __bf16* __restrict__ P2, const __bf16* __restrict__ Q2, long long ldq2, int nk2,
                          __bf16* __restrict__ gates, const float* __restrict__ c_t, const float* __restrict__ c_prev,
-                         float* __restrict__ dc_carry, int has_next, int H, int n_mt, int n_pt)
+                         float* __restrict__ dc_carry, int has_next, int H, int n_mt, int n_pt,
+                         float drop_p, uint32_t drop_seed, long long drop_row0)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using T = Tile<2, 2>;
@@ -219,6 +232,22 @@ void gen_bwd_cell_kernel(const __bf16* __restrict__ P1, const __bf16* __restrict
     f32x16 acc[2][2];
     zero_acc<2, 2>(acc);
     mainloop<2, 2>(P1 + (long long)pt * T::TP * (nk1 * BK), (long long)nk1 * BK, Q1 + row0 * ldq1, ldq1, nk1, lds, acc, wave, lane);
+    const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
+    const uint32_t thresh24 = (uint32_t)(drop_p * 16777216.0f);
+    if (thresh24) {
+        // the first contraction is the gradient of the DROPPED copy of h (what the layer above read): through the mask
+        const float keep_scale = 1.0f / (1.0f - drop_p);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int u = pt * 128 + wp * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const uint32_t idx = (uint32_t)((drop_row0 + row0 + wq * 64 + j * 32 + lo) * H + u);
+                    acc[i][j][r] = gmt_keep(idx, drop_seed, thresh24) ? acc[i][j][r] * keep_scale : 0.f;
+                }
+    }
     if (nk2 > 0) {
         __syncthreads();                                        // the first contraction's last tile is read by everybody
         mainloop<2, 2>(P2 + (long long)pt * T::TP * (nk2 * BK), (long long)nk2 * BK, Q2 + row0 * ldq2, ldq2, nk2, lds, acc, wave, lane);
@@ -228,7 +257,6 @@ void gen_bwd_cell_kernel(const __bf16* __restrict__ P1, const __bf16* __restrict
     const char* Cp = (const char*)(c_prev + row0 * H + pt * 128);
     float* dcc = dc_carry + row0 * H + pt * 128;
 
-    const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
     using GI = RowImage<512>;
     using CI = RowImage<256>;
     const int rl = wq * 32 + lo;
@@ -373,6 +401,7 @@ extern "C" int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* a, hipStream_t 
     GMT_CHECK_ARG(a && a->cond_pre && a->w0 && a->w1 && a->bias1 && a->wh1 && a->bh1 && a->wh2 && a->bh2 && a->ends && a->out_seq);
     GMT_CHECK_ARG(a->x0 && a->x1 && a->c0 && a->c1 && a->pos && a->T >= 1);
     GMT_CHECK_ARG(a->H == 512 && a->B > 0 && a->B % 256 == 0 && (!a->tf_mask || a->target));
+    GMT_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f && (long long)a->T * a->B * a->H < 0xffffffffLL);
     const bool train = a->gates0 != nullptr;        // training: every step keeps its state (x0 / x1 / c0 / c1 have T+1 slots)
     GMT_CHECK_ARG(!train || (a->gates1 && a->y_all && a->oraw_all));
     const int H = a->H, B = a->B, K0 = H + 64, K1 = 2 * H;
@@ -392,11 +421,11 @@ extern "C" int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* a, hipStream_t 
         // layer 0: reads x0[cur] = [h0_{t-1} | u_t]; h0_t -> x0[nxt][:, :H] (next step's recurrence) and x1[cur][:, :H]
         hipLaunchKernelGGL(gen_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), G_LDS, stream, (const __bf16*)a->w0, x0c, ld0,
                            K0 / 32, (const __bf16*)a->cond_pre, (const float*)nullptr, a->c0 + cur * B * H,
-                           a->c0 + nxt * B * H, x0n, ld0, x1c, (long long)K1, g0, H, n_mt, n_pt);
+                           a->c0 + nxt * B * H, x0n, ld0, x1c, (long long)K1, g0, H, n_mt, n_pt, a->dropout_p, a->seed, (long long)t * B);
         // layer 1: reads x1[cur] = [h0_t | h1_{t-1}]; h1_t -> x1[nxt][:, H:]
         hipLaunchKernelGGL(gen_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), G_LDS, stream, (const __bf16*)a->w1, x1c, (long long)K1,
                            K1 / 32, (const __bf16*)nullptr, a->bias1, a->c1 + cur * B * H, a->c1 + nxt * B * H,
-                           x1n + H, (long long)K1, (__bf16*)nullptr, 0LL, g1, H, n_mt, n_pt);
+                           x1n + H, (long long)K1, (__bf16*)nullptr, 0LL, g1, H, n_mt, n_pt, 0.f, 0u, 0LL);
         head_args h;
         h.wh1 = (const __bf16*)a->wh1; h.bh1 = a->bh1; h.wh2 = a->wh2; h.bh2 = a->bh2;
         h.h = x1n + H; h.ldh = K1;
@@ -448,13 +477,13 @@ extern "C" int gmt_bf16_gen_rollout_bwd(const gmt_bf16_gen_bwd_args* a, hipStrea
                            (const __bf16*)a->w1T, (const __bf16*)b.dypre, (long long)HH, HH / BK,
                            (const __bf16*)a->whh1T, (const __bf16*)(g1 + (size_t)(has_next ? t + 1 : t) * B * 4 * H), 4LL * H,
                            has_next ? 4 * H / BK : 0, g1 + (size_t)t * B * 4 * H, a->c1 + (size_t)(t + 1) * B * H,
-                           a->c1 + (size_t)t * B * H, a->dc1, (int)has_next, H, n_mt, n_pt);
+                           a->c1 + (size_t)t * B * H, a->dc1, (int)has_next, H, n_mt, n_pt, 0.f, 0u, 0LL);
         // layer 0: dh0_t = da1_t W_ih_l1 + da0_{t+1} W_hh_l0
         hipLaunchKernelGGL(gen_bwd_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), GB_LDS, stream,
                            (const __bf16*)a->wih1T, (const __bf16*)(g1 + (size_t)t * B * 4 * H), 4LL * H, 4 * H / BK,
                            (const __bf16*)a->whh0T, (const __bf16*)(g0 + (size_t)(has_next ? t + 1 : t) * B * 4 * H), 4LL * H,
                            has_next ? 4 * H / BK : 0, g0 + (size_t)t * B * 4 * H, a->c0 + (size_t)(t + 1) * B * H,
-                           a->c0 + (size_t)t * B * H, a->dc0, (int)has_next, H, n_mt, n_pt);
+                           a->c0 + (size_t)t * B * H, a->dc0, (int)has_next, H, n_mt, n_pt, a->dropout_p, a->seed, (long long)t * B);
     }
     GMT_LAUNCH_CHECK();
     return GMT_OK;

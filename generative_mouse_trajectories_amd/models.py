@@ -139,7 +139,7 @@ class Generator(nn.Module):
         H = self.config.generator_hidden_dim
         B = start.shape[0]
         if self.bf16:
-            return self._rollout_bf16(start, end, z, target_tm, tf_mask, T, stop_distance, padded)
+            return self._rollout_bf16(start, end, z, target_tm, tf_mask, T, stop_distance, padded, dropout_seed)
         Bp = ops.pad_rows(B)
         cond = self._compute_condition(start, end, z)
         lp = self.lstm
@@ -167,13 +167,11 @@ class Generator(nn.Module):
             return out[:, :B], lens[:B]
         return out if padded else out[:, :B]
 
-    def _rollout_bf16(self, start, end, z, target_tm, tf_mask, T: int, stop_distance: float, padded: bool):
+    def _rollout_bf16(self, start, end, z, target_tm, tf_mask, T: int, stop_distance: float, padded: bool, dropout_seed=None):
         """H = 512 (BASELINE configs[2]): the rollout on the bf16 kernels, three launches per timestep
         (ops_bf16.gen_rollout under no_grad, ops_bf16.GenRolloutBf16Fn with BPTT otherwise)."""
         if stop_distance > 0:
             raise NotImplementedError('compute_dtype bf16: the in-kernel early stop is not built; use generate(early_exit=False)')
-        if self.training and float(self.config.lstm_dropout) > 0:
-            raise NotImplementedError('compute_dtype bf16: the generator rollout runs without inter-layer dropout (eval mode)')
         B = start.shape[0]
         H = self.config.generator_hidden_dim
         Bp = (B + ops_bf16.ROW_TILE - 1) // ops_bf16.ROW_TILE * ops_bf16.ROW_TILE
@@ -181,6 +179,10 @@ class Generator(nn.Module):
         lp = self.lstm
         if target_tm is not None:
             target_tm = _pad_batch(target_tm, Bp, 1).contiguous()
+        p_drop = float(self.config.lstm_dropout) if self.training else 0.0
+        if dropout_seed is None:
+            dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
+        drop = (p_drop, dropout_seed)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training rollout: every step's state is kept, BPTT in ops_bf16.GenRolloutBf16Fn
             w_ih0 = lp.weight_ih_l0
@@ -191,14 +193,14 @@ class Generator(nn.Module):
                                                   lp.bias_ih_l1 + lp.bias_hh_l1, self.output_layer[0].weight,
                                                   self.output_layer[0].bias, self.output_layer[2].weight,
                                                   self.output_layer[2].bias, self.initial_input.reshape(3),
-                                                  _pad_batch(start, Bp, 0), _pad_batch(end, Bp, 0), target_tm, tf_list, T)
+                                                  _pad_batch(start, Bp, 0), _pad_batch(end, Bp, 0), target_tm, tf_list, T, drop)
             return out if padded else out[:, :B]
         out = ops_bf16.gen_rollout(cond, (lp.weight_ih_l0, lp.weight_hh_l0, lp.bias_ih_l0, lp.bias_hh_l0,
                                           lp.weight_ih_l1, lp.weight_hh_l1, lp.bias_ih_l1, lp.bias_hh_l1),
                                    (self.output_layer[0].weight, self.output_layer[0].bias,
                                     self.output_layer[2].weight, self.output_layer[2].bias),
                                    self.initial_input.reshape(3), _pad_batch(start, Bp, 0), _pad_batch(end, Bp, 0),
-                                   target_tm, tf_mask, T)
+                                   target_tm, tf_mask, T, drop)
         return out if padded else out[:, :B]
 
     def forward_tm(self, start, end, z, target_sequences: torch.Tensor, tf_mask: Sequence[bool],

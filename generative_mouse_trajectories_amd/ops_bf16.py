@@ -255,7 +255,7 @@ def gen_weights(w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, wh1):
 
 
 @torch.no_grad()
-def gen_rollout(cond, lstm_params, head, init_in, starts, ends, target_tm, tf_mask, T: int) -> torch.Tensor:
+def gen_rollout(cond, lstm_params, head, init_in, starts, ends, target_tm, tf_mask, T: int, drop=(0.0, 0)) -> torch.Tensor:
     """cond [B, H] fp32 (condition encoder output), lstm_params = (w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1),
     head = (W1 [H/2, H], b1, W2 [3, H/2], b2), init_in [3], starts / ends [B, 2], target_tm [T, B, 3] or None, tf_mask uint8
     [T] (device) or None -> out [T, B, 3] fp32 (dx, dy, dt).  B % 256 == 0, H == 512."""
@@ -286,6 +286,7 @@ def gen_rollout(cond, lstm_params, head, init_in, starts, ends, target_tm, tf_ma
     (a.cond_pre, a.w0, a.w1, a.bias1, a.wh1, a.bh1, a.wh2, a.bh2, a.ends, a.target, a.tf_mask) = [L_.ptr(t) for t in keep]
     a.out_seq, a.x0, a.x1, a.c0, a.c1, a.pos = (L_.ptr(t) for t in (out, x0, x1, c0, c1, pos))
     a.T, a.B, a.H = T, B, H
+    a.dropout_p, a.seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
     g_exec = 2.0 * (4 * H * (H + 7) + 4 * H * 2 * H + (H // 2) * H + 3 * (H // 2))
     L_.call('gmt_bf16_gen_rollout_fwd', ctypes.byref(a), L_.stream(), label='bf16_gen_rollout', flops=g_exec * T * B)
     return out
@@ -304,7 +305,7 @@ class GenRolloutBf16Fn(torch.autograd.Function):
     BPTT sweep (gmt_bf16_gen_rollout_bwd) followed by the weight-gradient GEMMs over all T*B row-steps."""
 
     @staticmethod
-    def forward(ctx, g0, w_u, w_hh0, w_ih1, w_hh1, bias1, wh1, bh1, wh2, bh2, init_in, starts, ends, target_tm, tf_list, T):
+    def forward(ctx, g0, w_u, w_hh0, w_ih1, w_hh1, bias1, wh1, bh1, wh2, bh2, init_in, starts, ends, target_tm, tf_list, T, drop):
         from ._lib import GenBf16Args
         import ctypes
         B = g0.shape[0]
@@ -352,11 +353,12 @@ class GenRolloutBf16Fn(torch.autograd.Function):
             a.out_seq, a.x0, a.x1, a.c0, a.c1, a.pos = (L_.ptr(t) for t in (out, x0, x1, c0, c1, pos))
             a.gates0, a.gates1, a.y_all, a.oraw_all = (L_.ptr(t) for t in (gates0, gates1, y_all, oraw))
             a.T, a.B, a.H = T, B, H
+            a.dropout_p, a.seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
             g_exec = 2.0 * (4 * H * (H + 7) + 4 * H * 2 * H + (H // 2) * H + 3 * (H // 2))
             L_.call('gmt_bf16_gen_rollout_fwd', ctypes.byref(a), L_.stream(), label='bf16_gen_rollout_train', flops=g_exec * T * B)
         ctx.save_for_backward(w_u, w_hh0, w_ih1, w_hh1, wh1, wh2)
         ctx.bufs = (x0, x1, c0, c1, gates0, gates1, y_all, oraw)
-        ctx.cfg = (T, B, H, [bool(b) for b in tf_list] if tf_list is not None else [False] * T)
+        ctx.cfg = (T, B, H, [bool(b) for b in tf_list] if tf_list is not None else [False] * T, (float(drop[0]), int(drop[1]) & 0xFFFFFFFF))
         return out
 
     @staticmethod
@@ -369,7 +371,7 @@ class GenRolloutBf16Fn(torch.autograd.Function):
         w_u, w_hh0, w_ih1, w_hh1, wh1, wh2 = ctx.saved_tensors
         x0, x1, c0, c1, gates0, gates1, y_all, oraw = ctx.bufs
         ctx.bufs = None
-        T, B, H, tf = ctx.cfg
+        T, B, H, tf, drop = ctx.cfg
         dev = d_out.device
         p = slab_perm(H, dev)
         HH = H // 2
@@ -394,6 +396,7 @@ class GenRolloutBf16Fn(torch.autograd.Function):
              gates0, gates1, c0, c1, x0, y_all, oraw, d_out, w1T, whh1T, wih1T, whh0T, wu8, wh2_c, dypre, d_o, d_in0, dc0, dc1, pc)]
         a.tf_mask_host = ctypes.cast(tf_host, ctypes.c_void_p)
         a.T, a.B, a.H = T, B, H
+        a.dropout_p, a.seed = drop
         g_exec = 2.0 * (4 * H * (H + 7) + 4 * H * 2 * H + (H // 2) * H + 3 * (H // 2))
         L_.call('gmt_bf16_gen_rollout_bwd', ctypes.byref(a), L_.stream(), label='bf16_gen_bptt', flops=g_exec * T * B)
         M = T * B
@@ -412,7 +415,7 @@ class GenRolloutBf16Fn(torch.autograd.Function):
         d_wh2 = d_o.view(M, 3).t() @ y_all.view(M, HH).float()
         d_bh2 = d_o.view(M, 3).sum(0)
         return (d_g0, d_w_u, d_w_hh0, d_w_ih1, d_w_hh1, d_bias1, d_wh1, d_bh1, d_wh2, d_bh2, d_in0.sum(0),
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -405,6 +405,8 @@ typedef struct gmt_bf16_gen_args {
     void* y_all;                  /* [T][B][H/2] bf16: head activation after LeakyReLU */
     float* oraw_all;              /* [T][B]: pre-softplus dt logit */
     int T, B, H;
+    float dropout_p;              /* inter-layer dropout of nn.LSTM(dropout=0.1), RG.py:451-457; 0 = off */
+    unsigned int seed;            /* mask = f(seed, (t*B + row)*H + unit): regenerated by the backward launch */
 } gmt_bf16_gen_args;
 #define GMT_BF16_GEN_X0_TRAIN_WIDTH 768
 int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* args, hipStream_t stream);
@@ -428,6 +430,7 @@ typedef struct gmt_bf16_gen_bwd_args {
     float* dc0; float* dc1; float* p_carry;
     const unsigned char* tf_mask_host;
     int T, B, H;
+    float dropout_p; unsigned int seed;   /* as in the forward launch */
 } gmt_bf16_gen_bwd_args;
 int gmt_bf16_gen_rollout_bwd(const gmt_bf16_gen_bwd_args* args, hipStream_t stream);
 

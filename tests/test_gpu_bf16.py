@@ -248,8 +248,8 @@ def test_bf16_generator_rollout_vs_fp64_oracle():
             assert e <= 3e-2
 
 
-@pytest.mark.parametrize('head_shift,bar', [(3.0, 6e-2), (0.0, 2e-1)])
-def test_bf16_generator_bptt_vs_fp64_oracle(head_shift, bar):
+@pytest.mark.parametrize('head_shift,bar,p_drop', [(3.0, 6e-2, 0.0), (0.0, 2e-1, 0.0), (3.0, 6e-2, 0.1)])
+def test_bf16_generator_bptt_vs_fp64_oracle(head_shift, bar, p_drop):
     """The training rollout + BPTT at H = 512 (three reverse launches per timestep, weight gradients as GEMMs over all T*B
     row-steps) against the fp64 oracle: a fixed random linear functional of the outputs, free-running and with a mixed
     teacher-forcing mask, every generator parameter.
@@ -257,15 +257,20 @@ def test_bf16_generator_bptt_vs_fp64_oracle(head_shift, bar):
     comparison then measures the sweep itself: 0.3-2.3 % of each gradient's max-norm (bar 6e-2, as for the critic).
     head_shift = 0 (the generated parameters): an untrained head's pre-activations straddle zero, a bf16-sized forward error
     flips the LeakyReLU branch of ~1 % of the units and every gradient inherits 2-10 % from that (bar 2e-1) - a property of
-    comparing a piecewise-linear net across precisions, also visible with T = 1."""
+    comparing a piecewise-linear net across precisions, also visible with T = 1.
+    p_drop = 0.1: nn.LSTM's inter-layer dropout (RG.py:451-457) as the counter-based mask inside the step kernels, forward and
+    BPTT; the oracle is handed the replayed mask."""
     import generative_mouse_trajectories_amd as gmt
     over = dict(latent_dim=16, generator_hidden_dim=512, discriminator_hidden_dim=32)
     cfg = gmt.Config()
     for k, v in over.items():
         setattr(cfg, k, v)
     cfg.compute_dtype = 'bf16'
-    cfg.lstm_dropout = 0.0
+    cfg.lstm_dropout = p_drop
     Bs, T, seed = 200, 12, 121
+    from generative_mouse_trajectories_amd import ops
+    DSEED = 777
+    mask = ops.dropout_keep_mask(T, 256, 512, p_drop, DSEED)[:, :Bs] if p_drop > 0 else None
     G = gmt.Generator(cfg)
     pg = PG.make_generator_params(O.OracleConfig(**over), seed)
     pg['output_layer.0.bias'] = pg['output_layer.0.bias'] + np.float32(head_shift)
@@ -276,10 +281,11 @@ def test_bf16_generator_bptt_vs_fp64_oracle(head_shift, bar):
     R = torch.randn(Bs, T, 3, generator=torch.Generator().manual_seed(seed + 3))
     for tf in ([False] * T, [True, False, False, True, False, True, True, False, False, False, True, False]):
         G.zero_grad()
-        out, _ = G(b['starts'].to(DEV), b['ends'].to(DEV), z.to(DEV), b['sequences'].to(DEV), tf_mask=tf)
+        out, _ = G(b['starts'].to(DEV), b['ends'].to(DEV), z.to(DEV), b['sequences'].to(DEV), tf_mask=tf, dropout_seed=DSEED)
         (out * R.to(DEV)).sum().backward()
         P64 = {k: H.t(v, torch.float64).requires_grad_(True) for k, v in pg.items()}
-        ref = O.generator_forward(P64, b['starts'].double(), b['ends'].double(), z.double(), b['sequences'].double(), tf)
+        ref = O.generator_forward(P64, b['starts'].double(), b['ends'].double(), z.double(), b['sequences'].double(), tf,
+                                  dropout_mask=None if mask is None else mask.double())
         keys = list(P64.keys())
         gs = dict(zip(keys, torch.autograd.grad((ref * R.double()).sum(), [P64[k] for k in keys], allow_unused=True)))
         err = {}
@@ -288,7 +294,7 @@ def test_bf16_generator_bptt_vs_fp64_oracle(head_shift, bar):
                 continue
             err[k] = H.relerr(prm.grad.cpu().reshape(gs[k].shape), gs[k])
         kmax = max(err, key=lambda k: err[k])
-        print(f'bf16 generator BPTT head_shift={head_shift} tf={sum(tf)}/{T}: out {H.relerr(out.detach().cpu(), ref.detach()):.1e}, '
+        print(f'bf16 generator BPTT head_shift={head_shift} dropout={p_drop} tf={sum(tf)}/{T}: out {H.relerr(out.detach().cpu(), ref.detach()):.1e}, '
               f'worst gradient {err[kmax]:.1e} ({kmax})')
         for k, v in err.items():
             assert v <= bar, (k, v)
@@ -298,10 +304,13 @@ def test_bf16_generator_refuses_what_is_not_built():
     import generative_mouse_trajectories_amd as gmt
     cfg = gmt.Config()
     cfg.generator_hidden_dim, cfg.discriminator_hidden_dim, cfg.compute_dtype = 512, 32, 'bf16'
-    G = gmt.Generator(cfg).to(DEV).train()               # lstm_dropout 0.1 in training mode: the fused mask is not built here
-    s = torch.rand(4, 2, device=DEV)
-    with pytest.raises(NotImplementedError):
-        G(s, s + 0.1, torch.randn(4, cfg.latent_dim, device=DEV), torch.zeros(4, 8, 3, device=DEV))
+    cfg.max_generation_steps = 8
+    G = gmt.Generator(cfg).to(DEV).eval()
+    s0 = torch.rand(4, 2, device=DEV)
+    with pytest.raises(NotImplementedError):             # the in-kernel early stop of generate() is fp32-path only
+        G.generate(s0, s0 + 0.1, early_exit=True)
+    out, lengths = G.generate(s0, s0 + 0.1)              # the default form runs
+    assert out.shape[0] == 4 and out.shape[2] == 3 and lengths.shape == (4,)
 
 
 def _gp_case(Hd, Bs, T, seed, dt_scale):
