@@ -423,3 +423,52 @@ def test_bf16_gradient_penalty_step_kernels():
     H.assert_close(torch.cat([hfin[0], hfin[1]], 1), hfin32, 1e-2, 'hhat_final')
     H.assert_close(unit_major(gg.view(L, B, 8 * Hd)), gg32, 1e-2, 'adjoint of the saved gates')
     H.assert_close(planes(gc), gc32, 1e-2, 'adjoint of the saved cell states')
+
+
+def test_bf16_train_steps_vs_fp64_oracle():
+    """One full D step (with the gradient penalty on a quarter of the batch) and one G step of the Trainer with BOTH networks
+    at H = 512 on the bf16 kernels (BASELINE configs[2]'s width; T = 16, 256 full-length trajectories, time steps x 50 so the
+    features are O(1), dropout off for a deterministic comparison): every returned metric against the oracle's step functions
+    (RG.py:913-1118) in fp64.  Bars: 5e-2 on the Wasserstein / score / auxiliary-loss metrics (absolute floor 5e-3: the
+    untrained scores are ~1e-2), 1.5e-1 on the penalty (a squared gradient norm, which bf16 noise inflates - see
+    test_bf16_gradient_penalty_vs_fp64_oracle)."""
+    import generative_mouse_trajectories_amd as gmt
+    over = dict(latent_dim=16, generator_hidden_dim=512, discriminator_hidden_dim=512)
+    cfg = gmt.Config()
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    cfg.lstm_dropout = cfg.head_dropout = 0.0
+    cfg.compute_dtype = 'bf16'
+    oc = O.OracleConfig(**over)
+    pg = PG.make_generator_params(oc, 141)
+    pd, bd = PG.make_discriminator_params(oc, 142)
+    G, D = gmt.Generator(cfg), gmt.Discriminator(cfg)
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in pg.items()}, strict=True)
+    sd = {k: torch.from_numpy(v) for k, v in pd.items()}
+    sd.update({k: torch.from_numpy(v) for k, v in bd.items()})
+    D.load_state_dict(sd, strict=True)
+    tr = gmt.Trainer(G.to(DEV).train(), D.to(DEV).train(), cfg, torch.device(DEV), '/tmp/runs_gpu_bf16')
+    tr.epoch = 30
+    Bs, T = 256, 16
+    b = H.batch_t(Bs, T, 143, [T] * Bs, torch.float32)
+    b['sequences'][:, :, 2] *= 50.0
+    g = torch.Generator().manual_seed(144)
+    nb = -(-Bs // 4)
+    noise = {'z': torch.randn(Bs, 16, generator=g), 'gp_idx': torch.randperm(Bs, generator=g), 'alpha': torch.rand(nb, generator=g)}
+    zg = torch.randn(Bs, 16, generator=g)
+    mask_tf = [bool(v) for v in (np.random.default_rng(145).random(T) < 0.7)]
+    m_d = tr.train_discriminator_step(b, dict(noise))
+    m_g = tr.train_generator_step(b, {'z': zg, 'tf_mask': mask_tf})
+    dt = torch.float64
+    Pg = {k: H.t(v, dt) for k, v in pg.items()}
+    Pd = {k: H.t(v, dt) for k, v in pd.items()}
+    Bd = {k: H.t(v, dt) for k, v in bd.items()}
+    bb = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in b.items()}
+    md, _, _ = O.discriminator_step(Pg, Pd, Bd, {}, bb, {'z': noise['z'].to(dt), 'gp_idx': noise['gp_idx'], 'alpha': noise['alpha'].to(dt)}, oc, 0)
+    mg, _, _ = O.generator_step(Pg, Pd, Bd, {}, bb, {'z': zg.to(dt)}, oc, mask_tf, tr.get_teacher_forcing_ratio())
+    print('bf16 D step:', {k: (round(m_d[k], 5), round(float(v), 5)) for k, v in md.items()})
+    print('bf16 G step:', {k: (round(m_g[k], 5), round(float(v), 5)) for k, v in mg.items()})
+    for got, ref in ((m_d, md), (m_g, mg)):
+        for k, v in ref.items():
+            bar = 1.5e-1 if k == 'd_gp' else 5e-2
+            assert abs(got[k] - v) <= bar * abs(v) + 5e-3, (k, got[k], v)
