@@ -205,61 +205,60 @@ def bench_config5(args, dev):
 
 
 def bench_config3(args, dev):
-    """BASELINE.json configs[2] (B=4096, T=256, H=512, bf16 operands / fp32 accumulation) - PARTIAL.  What exists at this
-    width is the critic (ops_bf16: forward, parameter and input gradients, inter-layer dropout); the generator rollout and
-    the gradient penalty's double backward are not built at H=512, so there is no trained-trajectories/s figure.  Timed here:
-    the critic's share of one D step - forward + backward with parameter gradients over real + fake = 2 x B trajectories of
-    257 points, 6 F_D of the 4 F_G + 8.375 F_D (= 55.19 GFLOP) a trained trajectory costs."""
+    """BASELINE.json configs[2]: B=4096, T=256, H_g = H_d = 512, bf16 operands / fp32 accumulation (state, parameter gradients,
+    master weights and Adam in fp32).  The same step as config 2 - one D step + one G step, gradient penalty every 4th D step
+    on 25 % of the batch, reference dropout on - on the bf16 kernel family (ops_bf16: hoisted GEMMs + one launch per timestep).
+    F_iter = 4 F_G + 8.375 F_D = 55.19 GFLOP per trained trajectory; peak = dense bf16 2.5 PFLOP/s."""
     import generative_mouse_trajectories_amd as gmt
     from generative_mouse_trajectories_amd import _lib
     B, T, Hd = args.batch, 256, 512
     cfg = gmt.Config()
-    cfg.discriminator_hidden_dim, cfg.generator_hidden_dim, cfg.latent_dim = Hd, HID, LATENT
+    cfg.discriminator_hidden_dim, cfg.generator_hidden_dim, cfg.latent_dim = Hd, Hd, LATENT
     cfg.compute_dtype = 'bf16'
     torch.manual_seed(0)
-    D = gmt.Discriminator(cfg).to(dev).train()
-    g = torch.Generator().manual_seed(1234)
-    rows = 2 * B                                                   # real + fake in one critic call, as the trainer does
-    pos = (torch.rand(1, rows, 2, generator=g) + torch.cumsum(torch.randn(T + 1, rows, 2, generator=g) * 0.01, 0)).to(dev)
-    dts = (torch.rand(T + 1, rows, generator=g) * 0.02 + 0.004).to(dev)
-    lens = torch.full((rows,), T + 1, dtype=torch.int32, device=dev)
+    G, D = gmt.Generator(cfg).to(dev), gmt.Discriminator(cfg).to(dev)
+    tr = gmt.Trainer(G, D, cfg, dev, log_dir=os.path.join('/tmp', 'gmt_bench_runs'))
+    tr.epoch = cfg.teacher_forcing_decay_epochs     # steady state: teacher-forcing ratio 0
+    tr.overlap_g_forward = False
+    G.train(); D.train()
+    batch = synthetic_batch(B, T, 1234, dev)
+    tf_mask = [False] * T
 
     def step():
-        D.zero_grad(set_to_none=True)
-        D.forward_tm(pos, dts, lens).mean().backward()
+        tr.train_discriminator_step(batch)
+        tr.train_generator_step(batch, {'tf_mask': tf_mask})
 
     steps = args.steps if args.steps_given else 4
-    warm = args.warmup if args.warmup_given else 2
-    for _ in range(max(1, warm)):
+    warm = args.warmup if args.warmup_given else 4
+    for _ in range(max(1, warm - 4)):
         step()
     torch.cuda.synchronize()
     _lib.profile_start()
-    step()
+    for _ in range(4):                                             # the per-kernel table: one gradient-penalty period
+        step()
     torch.cuda.synchronize()
     prof = _lib.profile_stop()
-    roof, table = roofline_of_dominant(prof, 1, rows, PEAK_BF16_MFMA_TFLOPS)
-    torch.cuda.synchronize()
+    roof, table = roofline_of_dominant(prof, 4, B, PEAK_BF16_MFMA_TFLOPS)
     _lib.profile_start(only=[roof['kernel']])
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    roof_timed, _ = roofline_of_dominant(_lib.profile_stop(), steps, rows, PEAK_BF16_MFMA_TFLOPS)
+    roof_timed, _ = roofline_of_dominant(_lib.profile_stop(), steps, B, PEAK_BF16_MFMA_TFLOPS)
     roof_timed['all_kernels_ms_per_step'] = roof['all_kernels_ms_per_step']
-    d_tok = 2 * (9 * Hd + Hd * Hd) + 32 * Hd * Hd + 48 * Hd * Hd
-    F_D = (T + 1) * d_tok + 2 * (2 * Hd * Hd + Hd * Hd / 2 + Hd / 2)
-    flops = 3.0 * F_D * rows
-    out = {'metric': 'config 3 PARTIAL: critic forward + backward (parameter gradients) over real + fake, trajectories/s',
-           'value': rows / dt, 'unit': 'critic trajectories/s', 'complete_train_step': False, 'n_gpus': 1, 'steps': steps,
-           'warmup': warm, 'ms_per_step': dt * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-           'dtype': 'bf16 operands / f32 accumulate, state and parameter gradients', 'data': 'synthetic',
-           'config': {'workload': f'BASELINE configs[2] critic share of a D step: Discriminator (H={Hd}, 2-layer BiLSTM, '
-                                  f'lstm_dropout {cfg.lstm_dropout}) forward + backward on {rows} trajectories x {T + 1} points',
-                      'global_batch': B, 'seq_len': T, 'not_built_at_this_width': ['generator rollout + BPTT', 'gradient penalty']},
-           'algorithmic_tflop_per_step': flops / 1e12, 'step_tflops': flops / dt / 1e12,
-           'frac_of_bf16_mfma_peak': flops / dt / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-           'share_of_a_trained_trajectory': '6 F_D of 4 F_G + 8.375 F_D = 33.17 of 55.19 GFLOP',
+    fl = flops_per_trajectory(T, Hd, Hd)[0]
+    out = {'metric': 'GAN trajectories/sec trained (B=4096,T=256,H=512, bf16 compute / fp32 accum)', 'value': B / dt,
+           'unit': 'trajectories/s', 'n_gpus': 1, 'steps': steps, 'warmup': warm, 'ms_per_step': dt * 1e3,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'bf16 operands / f32 accumulate, state, parameter gradients and optimizer', 'data': 'synthetic',
+           'config': {'workload': f'BASELINE configs[2]: WGAN-GP train step (D step + G step), B={B}, T={T}, H_g=H_d={Hd}, latent {LATENT}, '
+                                  'n_critic 1, GP every 4th D step on 25% of the batch (dropout-free critic inside the penalty), '
+                                  'teacher-forcing ratio 0', 'global_batch': B, 'seq_len': T, 'parallelism': 'dp1',
+                      'lstm_dropout': cfg.lstm_dropout, 'head_dropout': cfg.head_dropout},
+           'model_flops_per_trajectory': fl, 'step_tflops': fl * B / dt / 1e12,
+           'frac_of_bf16_mfma_peak': fl * B / dt / 1e12 / PEAK_BF16_MFMA_TFLOPS,
            'roofline': roof_timed, 'kernels': table, 'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated() / 1e9}
     print(json.dumps(out), flush=True)
 
