@@ -215,6 +215,7 @@ void gen_head_kernel(head_args a)
 constexpr int GB_G_OFF = 0, GB_C_OFF = 64 * 512, GB_CP_OFF = GB_C_OFF + 64 * 256;          // as the critic's backward step
 constexpr int GB_LDS = 64 * 1024;
 
+template <int NQB>
 __global__ __launch_bounds__(NTHREADS, 2)
 void gen_bwd_cell_kernel(const __bf16* __restrict__ P1, const __bf16* __restrict__ Q1, long long ldq1, int nk1,
                          const __bf16* __restrict__ P2, const __bf16* __restrict__ Q2, long long ldq2, int nk2,
@@ -223,34 +224,34 @@ void gen_bwd_cell_kernel(const __bf16* __restrict__ P1, const __bf16* __restrict
                          float drop_p, uint32_t drop_seed, long long drop_row0)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    using T = Tile<2, 2>;
+    using T = Tile<2, NQB>;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int d, pt, mt;
     patch_of_block(blockIdx.x, gridDim.x, n_mt, n_pt, d, pt, mt);
     const long long row0 = (long long)mt * T::TQ;
-    f32x16 acc[2][2];
-    zero_acc<2, 2>(acc);
-    mainloop<2, 2>(P1 + (long long)pt * T::TP * (nk1 * BK), (long long)nk1 * BK, Q1 + row0 * ldq1, ldq1, nk1, lds, acc, wave, lane);
+    f32x16 acc[2][NQB];
+    zero_acc<2, NQB>(acc);
+    mainloop<2, NQB>(P1 + (long long)pt * T::TP * (nk1 * BK), (long long)nk1 * BK, Q1 + row0 * ldq1, ldq1, nk1, lds, acc, wave, lane);
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
     const uint32_t thresh24 = (uint32_t)(drop_p * 16777216.0f);
     if (thresh24) {
         // the first contraction is the gradient of the DROPPED copy of h (what the layer above read): through the mask
         const float keep_scale = 1.0f / (1.0f - drop_p);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NQB; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int u = pt * 128 + wp * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const uint32_t idx = (uint32_t)((drop_row0 + row0 + wq * 64 + j * 32 + lo) * H + u);
+                    const uint32_t idx = (uint32_t)((drop_row0 + row0 + wq * (32 * NQB) + j * 32 + lo) * H + u);
                     acc[i][j][r] = gmt_keep(idx, drop_seed, thresh24) ? acc[i][j][r] * keep_scale : 0.f;
                 }
     }
     if (nk2 > 0) {
         __syncthreads();                                        // the first contraction's last tile is read by everybody
-        mainloop<2, 2>(P2 + (long long)pt * T::TP * (nk2 * BK), (long long)nk2 * BK, Q2 + row0 * ldq2, ldq2, nk2, lds, acc, wave, lane);
+        mainloop<2, NQB>(P2 + (long long)pt * T::TP * (nk2 * BK), (long long)nk2 * BK, Q2 + row0 * ldq2, ldq2, nk2, lds, acc, wave, lane);
     }
     char* Gt = (char*)(gates + row0 * 4 * H + pt * 512);
     const char* Ct = (const char*)(c_t + row0 * H + pt * 128);
@@ -261,9 +262,9 @@ void gen_bwd_cell_kernel(const __bf16* __restrict__ P1, const __bf16* __restrict
     using CI = RowImage<256>;
     const int rl = wq * 32 + lo;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        auto rowmap = [j](int r) { return (r >> 5) * 64 + j * 32 + (r & 31); };
-        const int brow = wq * 64 + j * 32 + lo;
+    for (int j = 0; j < NQB; ++j) {
+        auto rowmap = [j](int r) { return (r >> 5) * (32 * NQB) + j * 32 + (r & 31); };
+        const int brow = wq * (32 * NQB) + j * 32 + lo;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             auto gcol = [i](int c) { return (((c >> 4) * 2 + i) * 128) * 2 + (c & 15) * 16; };
@@ -446,10 +447,12 @@ extern "C" int gmt_bf16_gen_rollout_bwd(const gmt_bf16_gen_bwd_args* a, hipStrea
     GMT_CHECK_ARG(a && a->gates0 && a->gates1 && a->c0 && a->c1 && a->x0 && a->y_all && a->oraw_all && a->d_out);
     GMT_CHECK_ARG(a->w1T && a->whh1T && a->wih1T && a->whh0T && a->w_u && a->wh2 && a->dypre_all && a->d_o && a->d_in0);
     GMT_CHECK_ARG(a->dc0 && a->dc1 && a->p_carry && a->tf_mask_host && a->H == 512 && a->B > 0 && a->B % 256 == 0 && a->T >= 1);
-    using T2 = Tile<2, 2>;
     const int H = a->H, B = a->B, T = a->T, HH = H / 2;
-    const int n_mt = B / T2::TQ, n_pt = H / T2::TP;
-    if (hipFuncSetAttribute((const void*)gen_bwd_cell_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS) != hipSuccess)
+    const int n_pt = H / 128;
+    const bool small = (B / 128) * n_pt < 512;                 // 64-row tiles unless 128-row ones fill the chip twice over
+    const int n_mt = B / (small ? 64 : 128);
+    auto cell = small ? gen_bwd_cell_kernel<1> : gen_bwd_cell_kernel<2>;
+    if (hipFuncSetAttribute((const void*)cell, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS) != hipSuccess)
         return GMT_ERR_HIP;
     const size_t ld0 = GMT_BF16_GEN_X0_TRAIN_WIDTH;
     __bf16* g0 = (__bf16*)a->gates0; __bf16* g1 = (__bf16*)a->gates1;
@@ -473,13 +476,13 @@ extern "C" int gmt_bf16_gen_rollout_bwd(const gmt_bf16_gen_bwd_args* a, hipStrea
         hipLaunchKernelGGL(gen_bwd_book_kernel, dim3(B / 16), dim3(NTHREADS), 0, stream, b);
         if (t < 0) break;
         // layer 1: dh1_t = d(ypre_t) W1 + da1_{t+1} W_hh_l1
-        hipLaunchKernelGGL(gen_bwd_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), GB_LDS, stream,
+        hipLaunchKernelGGL(cell, dim3(n_mt * n_pt), dim3(NTHREADS), GB_LDS, stream,
                            (const __bf16*)a->w1T, (const __bf16*)b.dypre, (long long)HH, HH / BK,
                            (const __bf16*)a->whh1T, (const __bf16*)(g1 + (size_t)(has_next ? t + 1 : t) * B * 4 * H), 4LL * H,
                            has_next ? 4 * H / BK : 0, g1 + (size_t)t * B * 4 * H, a->c1 + (size_t)(t + 1) * B * H,
                            a->c1 + (size_t)t * B * H, a->dc1, (int)has_next, H, n_mt, n_pt, 0.f, 0u, 0LL);
         // layer 0: dh0_t = da1_t W_ih_l1 + da0_{t+1} W_hh_l0
-        hipLaunchKernelGGL(gen_bwd_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), GB_LDS, stream,
+        hipLaunchKernelGGL(cell, dim3(n_mt * n_pt), dim3(NTHREADS), GB_LDS, stream,
                            (const __bf16*)a->wih1T, (const __bf16*)(g1 + (size_t)t * B * 4 * H), 4LL * H, 4 * H / BK,
                            (const __bf16*)a->whh0T, (const __bf16*)(g0 + (size_t)(has_next ? t + 1 : t) * B * 4 * H), 4LL * H,
                            has_next ? 4 * H / BK : 0, g0 + (size_t)t * B * 4 * H, a->c0 + (size_t)(t + 1) * B * H,

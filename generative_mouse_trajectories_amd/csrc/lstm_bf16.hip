@@ -149,7 +149,7 @@ void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf
 // planes moving through LDS as whole rows; the carried dc (and the thin dh inputs) are read and written directly.
 constexpr int BWD_G_OFF = 0, BWD_C_OFF = 64 * 512, BWD_CP_OFF = BWD_C_OFF + 64 * 256;      // 32 + 16 + 16 KiB
 
-template <bool RAGGED>
+template <bool RAGGED, int NQB>
 __global__ __launch_bounds__(NTHREADS, 2)
 void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call, const __bf16* __restrict__ dHout,
                           const float* __restrict__ dh_fin, float* __restrict__ dc_carry, float* __restrict__ dh_carry,
@@ -157,7 +157,7 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
                           int L, int B, int H, int ndir, int step, int n_mt, int n_pt, float drop_p, uint32_t drop_seed)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    using T = Tile<2, 2>;
+    using T = Tile<2, NQB>;                                    // 128 units x 128 or 64 rows (the latter when B is small)
     const uint32_t thresh16 = (uint32_t)(drop_p * 65536.0f);
     const float keep_scale = 1.0f / (1.0f - drop_p);
     const int lane = threadIdx.x & 63;
@@ -180,9 +180,9 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
     float* dhc = dh_carry + ((long long)d * B + row0) * H + pt * 128;
     const float* dhf = dh_fin + ((long long)d * B + row0) * H + pt * 128;
 
-    f32x16 acc[2][2];
-    zero_acc<2, 2>(acc);
-    mainloop<2, 2>(WhhT + ((long long)d * H + (long long)pt * T::TP) * 4 * H, 4LL * H, Gn, ldg, has_next ? 4 * H / BK : 0,
+    f32x16 acc[2][NQB];
+    zero_acc<2, NQB>(acc);
+    mainloop<2, NQB>(WhhT + ((long long)d * H + (long long)pt * T::TP) * 4 * H, 4LL * H, Gn, ldg, has_next ? 4 * H / BK : 0,
                    lds, acc, wave, lane);
 
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
@@ -190,9 +190,9 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
     using CI = RowImage<256>;
     const int rl = wq * 32 + lo;                               // image row of this lane in every quarter
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        auto rowmap = [j](int r) { return (r >> 5) * 64 + j * 32 + (r & 31); };
-        const int brow = wq * 64 + j * 32 + lo;                // this lane's row within the tile
+    for (int j = 0; j < NQB; ++j) {
+        auto rowmap = [j](int r) { return (r >> 5) * (32 * NQB) + j * 32 + (r & 31); };
+        const int brow = wq * (32 * NQB) + j * 32 + lo;                // this lane's row within the tile
         bool valid = true;
         if (RAGGED) valid = t < lengths[row0 + brow];
 #pragma unroll
@@ -505,15 +505,19 @@ extern "C" int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const vo
                                        hipStream_t stream)
 {
     GMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || dh_out));
-    using T = Tile<2, 2>;
     GMT_CHECK_ARG(gates && c_all && dh_fin && dc_carry && w_hhT && L >= 1 && (ndir == 1 || ndir == 2));
-    GMT_CHECK_ARG(B > 0 && B % 256 == 0 && H > 0 && H % T::TP == 0 && (!ragged || (lengths && dh_carry)));
-    const int n_mt = B / T::TQ, n_pt = H / T::TP;
-    auto k = ragged ? lstm_step_bwd_kernel<true> : lstm_step_bwd_kernel<false>;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess)
+    GMT_CHECK_ARG(B > 0 && B % 256 == 0 && H > 0 && H % 128 == 0 && (!ragged || (lengths && dh_carry)));
+    // 128-row tiles when they fill the chip twice over (two workgroups per CU), 64-row tiles otherwise (B = 4096: 512 workgroups)
+    const int n_pt = H / 128;
+    const bool small = ndir * (B / 128) * n_pt < 512;
+    const int n_mt = B / (small ? 64 : 128);
+    auto k = small ? (ragged ? lstm_step_bwd_kernel<true, 1> : lstm_step_bwd_kernel<false, 1>)
+                   : (ragged ? lstm_step_bwd_kernel<true, 2> : lstm_step_bwd_kernel<false, 2>);
+    constexpr int BWD_LDS = 64 * 1024;                         // the epilogue images; the mainloop's stages need 48-64 KiB
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS) != hipSuccess)
         return GMT_ERR_HIP;
     for (int step = 0; step < L; ++step)
-        hipLaunchKernelGGL(k, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), T::LDS_BYTES, stream, (__bf16*)gates, c_all,
+        hipLaunchKernelGGL(k, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), BWD_LDS, stream, (__bf16*)gates, c_all,
                            (const __bf16*)dh_out, dh_fin, dc_carry, dh_carry, (const __bf16*)w_hhT, lengths, L, B, H, ndir, step,
                            n_mt, n_pt, drop_p, drop_seed);
     GMT_LAUNCH_CHECK();
