@@ -10,7 +10,10 @@ of a CU, so the persistent one-workgroup-per-32-rows kernels of `ops` do not app
 The critic body (kinematics -> feature encoder -> BiLSTM stack -> final hidden states, RG.py:757-778) is ONE autograd
 Function so that the big buffers are reused in place (gates -> d(pre-activation)).
 
-Not covered yet (documented in DESIGN.md section 7): the gradient penalty's double backward and the generator at H = 512."""
+The generator (RG.py:551-719) is the same idea with three launches per step (`gmt_bf16_gen_rollout_fwd/bwd`,
+`GenRolloutBf16Fn`), and the gradient penalty's double backward through the BiLSTM stack is `LSTMStackGPFn` /
+`LSTMStackBwdGPFn` over `gmt_bf16_lstm_layer_bwd_gp/_bwd2`.  Limits (refused loudly): generator
+H = 512 only, no in-kernel early stop, penalty on full-length batches with a dropout-free critic."""
 from __future__ import annotations
 
 from typing import List, Optional
