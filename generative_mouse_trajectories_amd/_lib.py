@@ -10,7 +10,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libgmt_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 ERRORS = {-1: 'bad argument (null pointer / shape / alignment)', -2: 'unsupported configuration',
@@ -83,6 +83,7 @@ _SIGS = {
     'gmt_bf16_wgrad_tn': [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, c_p],
     'gmt_bf16_lstm_layer_bwd_gp': [c_p] * 11 + [c_i] * 4 + [c_p],
     'gmt_bf16_lstm_layer_bwd2': [c_p] * 11 + [c_i] * 4 + [c_p],
+    'gmt_bf16_set_row_groups': [c_i],
     'gmt_dx_gemm_resident': [c_i, c_i],
     'gmt_dx_gemm': [c_p, c_p, c_p, c_p, c_f, c_ll, c_i, c_i, c_i, c_p],
     'gmt_traj_from_seq': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],

@@ -11,6 +11,7 @@
 // (slots 0-6 u_hi, 7-13 u_lo, both against W_u): they span 1e-3 .. 1e0 and steer the trajectory, 8 bits are not enough.
 // The condition term cond W_cond^T + b is constant over time and computed once by the caller (gmt_bf16_gemm_nt).
 #include "bf16_tile.h"
+#include "row_groups.h"
 #include "lstm_tile.h"      // gmt_keep: the generator's counter-based inter-layer dropout mask, as in the fp32 rollout
 
 namespace {
@@ -28,14 +29,14 @@ void gen_cell_kernel(const __bf16* __restrict__ W, const __bf16* __restrict__ X,
                      const __bf16* __restrict__ pre, const float* __restrict__ bias,
                      const float* __restrict__ c_prev, float* __restrict__ c_out,
                      __bf16* __restrict__ h0, long long ldh0, __bf16* __restrict__ h1, long long ldh1,
-                     __bf16* __restrict__ gates_out, int H, int n_mt, int n_pt, float drop_p, uint32_t drop_seed, long long drop_row0)
+                     __bf16* __restrict__ gates_out, int H, int mt0, int n_mt, int n_pt, float drop_p, uint32_t drop_seed, long long drop_row0)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int d, pt, mt;
     patch_of_block(blockIdx.x, gridDim.x, n_mt, n_pt, d, pt, mt);
-    const long long row0 = (long long)mt * G_TQ;
+    const long long row0 = (long long)(mt0 + mt) * G_TQ;         // this launch covers row tiles [mt0, mt0 + n_mt)
     const long long K = 32LL * nk32;
 
     f32x16 acc[4][2];
@@ -120,7 +121,7 @@ struct head_args {
     float* out_seq; float* pos; float* tf_pos;
     __bf16* u_next; long long ldu;                   // &x0_next[0][H]: 14 slots written per row
     __bf16* y_out; float* oraw_out;                  // training: [B][HH] head activation, [B] pre-softplus dt logit (or NULL)
-    int t, B, H;
+    int t, B, H, blk0;                               // blk0: first row tile of this launch (row groups)
 };
 
 __global__ __launch_bounds__(NTHREADS, 2)
@@ -129,7 +130,7 @@ void gen_head_kernel(head_args a)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long row0 = (long long)blockIdx.x * G_TQ;
+    const long long row0 = (long long)(a.blk0 + blockIdx.x) * G_TQ;
     const int HH = a.H / 2;
 
     f32x16 acc[4][2];
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(NTHREADS, 2)
 void gen_bwd_cell_kernel(const __bf16* __restrict__ P1, const __bf16* __restrict__ Q1, long long ldq1, int nk1,
                          const __bf16* __restrict__ P2, const __bf16* __restrict__ Q2, long long ldq2, int nk2,
                          __bf16* __restrict__ gates, const float* __restrict__ c_t, const float* __restrict__ c_prev,
-                         float* __restrict__ dc_carry, int has_next, int H, int n_mt, int n_pt,
+                         float* __restrict__ dc_carry, int has_next, int H, int mt0, int n_mt, int n_pt,
                          float drop_p, uint32_t drop_seed, long long drop_row0)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -229,7 +230,7 @@ void gen_bwd_cell_kernel(const __bf16* __restrict__ P1, const __bf16* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int d, pt, mt;
     patch_of_block(blockIdx.x, gridDim.x, n_mt, n_pt, d, pt, mt);
-    const long long row0 = (long long)mt * T::TQ;
+    const long long row0 = (long long)(mt0 + mt) * T::TQ;
     f32x16 acc[2][NQB];
     zero_acc<2, NQB>(acc);
     mainloop<2, NQB>(P1 + (long long)pt * T::TP * (nk1 * BK), (long long)nk1 * BK, Q1 + row0 * ldq1, ldq1, nk1, lds, acc, wave, lane);
@@ -326,7 +327,7 @@ struct book_args {
     __bf16* dypre; float* d_o;  // [B][HH] bf16, [B][3] fp32 out
     float* d_in0;               // [B][3] out (t = -1 only)
     int tf_t, tf_next;          // teacher-forcing flags of steps t and t+1 (host copies of the mask)
-    int t, B, H;
+    int t, B, H, blk0;          // blk0: first 16-row block of this launch (row groups)
 };
 
 __global__ __launch_bounds__(NTHREADS)
@@ -340,7 +341,7 @@ void gen_bwd_book_kernel(book_args a)
             *reinterpret_cast<bf16x8*>(wus + i * 8) = *reinterpret_cast<const bf16x8*>(a.w_u + (long long)i * 8);
     __syncthreads();
     for (int rr = 0; rr < 4; ++rr) {
-        const long long row = (long long)blockIdx.x * 16 + wave * 4 + rr;
+        const long long row = (long long)(a.blk0 + blockIdx.x) * 16 + wave * 4 + rr;
         float du[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (a.da0_next) {
             const __bf16* dr = a.da0_next + row * G4;
@@ -412,7 +413,8 @@ extern "C" int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* a, hipStream_t 
         hipFuncSetAttribute((const void*)gen_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess)
         return GMT_ERR_HIP;
     __bf16* x0 = (__bf16*)a->x0; __bf16* x1 = (__bf16*)a->x1;
-    for (int t = 0; t < a->T; ++t) {
+    const int ng = row_groups(B, G_TQ), g_mt = n_mt / ng;
+    const int rc = run_row_groups(ng, a->T, stream, [&](int g, int t, hipStream_t st) {
         const size_t cur = train ? t : (t & 1), nxt = train ? t + 1 : ((t & 1) ^ 1);
         __bf16* x0c = x0 + cur * B * ld0; __bf16* x0n = x0 + nxt * B * ld0;
         __bf16* x1c = x1 + cur * B * K1; __bf16* x1n = x1 + nxt * B * K1;
@@ -420,13 +422,13 @@ extern "C" int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* a, hipStream_t 
         __bf16* g0 = train ? (__bf16*)a->gates0 + (size_t)t * B * 4 * H : nullptr;
         __bf16* g1 = train ? (__bf16*)a->gates1 + (size_t)t * B * 4 * H : nullptr;
         // layer 0: reads x0[cur] = [h0_{t-1} | u_t]; h0_t -> x0[nxt][:, :H] (next step's recurrence) and x1[cur][:, :H]
-        hipLaunchKernelGGL(gen_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), G_LDS, stream, (const __bf16*)a->w0, x0c, ld0,
+        hipLaunchKernelGGL(gen_cell_kernel, dim3(g_mt * n_pt), dim3(NTHREADS), G_LDS, st, (const __bf16*)a->w0, x0c, ld0,
                            K0 / 32, (const __bf16*)a->cond_pre, (const float*)nullptr, a->c0 + cur * B * H,
-                           a->c0 + nxt * B * H, x0n, ld0, x1c, (long long)K1, g0, H, n_mt, n_pt, a->dropout_p, a->seed, (long long)t * B);
+                           a->c0 + nxt * B * H, x0n, ld0, x1c, (long long)K1, g0, H, g * g_mt, g_mt, n_pt, a->dropout_p, a->seed, (long long)t * B);
         // layer 1: reads x1[cur] = [h0_t | h1_{t-1}]; h1_t -> x1[nxt][:, H:]
-        hipLaunchKernelGGL(gen_cell_kernel, dim3(n_mt * n_pt), dim3(NTHREADS), G_LDS, stream, (const __bf16*)a->w1, x1c, (long long)K1,
+        hipLaunchKernelGGL(gen_cell_kernel, dim3(g_mt * n_pt), dim3(NTHREADS), G_LDS, st, (const __bf16*)a->w1, x1c, (long long)K1,
                            K1 / 32, (const __bf16*)nullptr, a->bias1, a->c1 + cur * B * H, a->c1 + nxt * B * H,
-                           x1n + H, (long long)K1, (__bf16*)nullptr, 0LL, g1, H, n_mt, n_pt, 0.f, 0u, 0LL);
+                           x1n + H, (long long)K1, (__bf16*)nullptr, 0LL, g1, H, g * g_mt, g_mt, n_pt, 0.f, 0u, 0LL);
         head_args h;
         h.wh1 = (const __bf16*)a->wh1; h.bh1 = a->bh1; h.wh2 = a->wh2; h.bh2 = a->bh2;
         h.h = x1n + H; h.ldh = K1;
@@ -435,9 +437,10 @@ extern "C" int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* a, hipStream_t 
         h.u_next = x0n + H; h.ldu = ld0;
         h.y_out = train ? (__bf16*)a->y_all + (size_t)t * B * (H / 2) : nullptr;
         h.oraw_out = train ? a->oraw_all + (size_t)t * B : nullptr;
-        h.t = t; h.B = B; h.H = H;
-        hipLaunchKernelGGL(gen_head_kernel, dim3(B / G_TQ), dim3(NTHREADS), G_LDS, stream, h);
-    }
+        h.t = t; h.B = B; h.H = H; h.blk0 = g * g_mt;
+        hipLaunchKernelGGL(gen_head_kernel, dim3(g_mt), dim3(NTHREADS), G_LDS, st, h);
+    });
+    if (rc != GMT_OK) return rc;
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }
@@ -457,7 +460,10 @@ extern "C" int gmt_bf16_gen_rollout_bwd(const gmt_bf16_gen_bwd_args* a, hipStrea
     const size_t ld0 = GMT_BF16_GEN_X0_TRAIN_WIDTH;
     __bf16* g0 = (__bf16*)a->gates0; __bf16* g1 = (__bf16*)a->gates1;
     const __bf16* x0 = (const __bf16*)a->x0;
-    for (int t = T - 1; t >= -1; --t) {
+    const int tile_rows = small ? 64 : 128;
+    const int ng = row_groups(B, tile_rows), g_mt = n_mt / ng;
+    const int rc = run_row_groups(ng, T + 1, stream, [&](int g, int step, hipStream_t st) {
+        const int t = T - 1 - step;
         const bool has_next = t < T - 1;
         book_args b;
         b.da0_next = has_next ? g0 + (size_t)(t + 1) * B * 4 * H : nullptr;
@@ -472,22 +478,23 @@ extern "C" int gmt_bf16_gen_rollout_bwd(const gmt_bf16_gen_bwd_args* a, hipStrea
         b.d_in0 = a->d_in0;
         b.tf_t = t >= 0 ? a->tf_mask_host[t] : 0;
         b.tf_next = has_next ? a->tf_mask_host[t + 1] : 0;
-        b.t = t; b.B = B; b.H = H;
-        hipLaunchKernelGGL(gen_bwd_book_kernel, dim3(B / 16), dim3(NTHREADS), 0, stream, b);
-        if (t < 0) break;
+        b.t = t; b.B = B; b.H = H; b.blk0 = g * (B / ng / 16);
+        hipLaunchKernelGGL(gen_bwd_book_kernel, dim3(B / ng / 16), dim3(NTHREADS), 0, st, b);
+        if (t < 0) return;
         // layer 1: dh1_t = d(ypre_t) W1 + da1_{t+1} W_hh_l1
-        hipLaunchKernelGGL(cell, dim3(n_mt * n_pt), dim3(NTHREADS), GB_LDS, stream,
+        hipLaunchKernelGGL(cell, dim3(g_mt * n_pt), dim3(NTHREADS), GB_LDS, st,
                            (const __bf16*)a->w1T, (const __bf16*)b.dypre, (long long)HH, HH / BK,
                            (const __bf16*)a->whh1T, (const __bf16*)(g1 + (size_t)(has_next ? t + 1 : t) * B * 4 * H), 4LL * H,
                            has_next ? 4 * H / BK : 0, g1 + (size_t)t * B * 4 * H, a->c1 + (size_t)(t + 1) * B * H,
-                           a->c1 + (size_t)t * B * H, a->dc1, (int)has_next, H, n_mt, n_pt, 0.f, 0u, 0LL);
+                           a->c1 + (size_t)t * B * H, a->dc1, (int)has_next, H, g * g_mt, g_mt, n_pt, 0.f, 0u, 0LL);
         // layer 0: dh0_t = da1_t W_ih_l1 + da0_{t+1} W_hh_l0
-        hipLaunchKernelGGL(cell, dim3(n_mt * n_pt), dim3(NTHREADS), GB_LDS, stream,
+        hipLaunchKernelGGL(cell, dim3(g_mt * n_pt), dim3(NTHREADS), GB_LDS, st,
                            (const __bf16*)a->wih1T, (const __bf16*)(g1 + (size_t)t * B * 4 * H), 4LL * H, 4 * H / BK,
                            (const __bf16*)a->whh0T, (const __bf16*)(g0 + (size_t)(has_next ? t + 1 : t) * B * 4 * H), 4LL * H,
                            has_next ? 4 * H / BK : 0, g0 + (size_t)t * B * 4 * H, a->c0 + (size_t)(t + 1) * B * H,
-                           a->c0 + (size_t)t * B * H, a->dc0, (int)has_next, H, n_mt, n_pt, a->dropout_p, a->seed, (long long)t * B);
-    }
+                           a->c0 + (size_t)t * B * H, a->dc0, (int)has_next, H, g * g_mt, g_mt, n_pt, a->dropout_p, a->seed, (long long)t * B);
+    });
+    if (rc != GMT_OK) return rc;
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }

@@ -17,6 +17,7 @@
 // last valid h, so h_all[L-1] is the final state), direction 1 holds zero state until t = len-1 (final state =
 // h_all[0]); the backward sweep writes dA = 0 for those row-steps.
 #include "bf16_tile.h"
+#include "row_groups.h"
 #include "lstm_tile.h"      // the counter-based dropout mask shared with the fp32 kernels (gmt_keep_pair_hash)
 
 namespace {
@@ -46,13 +47,14 @@ template <bool RAGGED>
 __global__ __launch_bounds__(NTHREADS, 2)
 void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf16* __restrict__ Hall,
                           __bf16* __restrict__ Hdrop, const __bf16* __restrict__ Whh, const int* __restrict__ lengths,
-                          int L, int B, int H, int ndir, int step, int n_mt, int n_pt, float drop_p, uint32_t drop_seed)
+                          int L, int B, int H, int ndir, int step, int mt0, int n_mt, int n_pt, float drop_p, uint32_t drop_seed)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int d, pt, mt;
     patch_of_block(blockIdx.x, gridDim.x, n_mt, n_pt, d, pt, mt);
+    mt += mt0;                                                  // this launch covers row tiles [mt0, mt0 + n_mt)
     const int t = d == 0 ? step : L - 1 - step;
     const int tprev = d == 0 ? t - 1 : t + 1;
     const bool has_prev = step > 0;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(NTHREADS, 2)
 void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call, const __bf16* __restrict__ dHout,
                           const float* __restrict__ dh_fin, float* __restrict__ dc_carry, float* __restrict__ dh_carry,
                           const __bf16* __restrict__ WhhT, const int* __restrict__ lengths,
-                          int L, int B, int H, int ndir, int step, int n_mt, int n_pt, float drop_p, uint32_t drop_seed)
+                          int L, int B, int H, int ndir, int step, int mt0, int n_mt, int n_pt, float drop_p, uint32_t drop_seed)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using T = Tile<2, NQB>;                                    // 128 units x 128 or 64 rows (the latter when B is small)
@@ -164,6 +166,7 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int d, pt, mt;
     patch_of_block(blockIdx.x, gridDim.x, n_mt, n_pt, d, pt, mt);
+    mt += mt0;
     const int t = d == 0 ? L - 1 - step : step;
     const int tnext = d == 0 ? t + 1 : t - 1;                  // processed by the previous launch of this sweep
     const int tprev = d == 0 ? t - 1 : t + 1;                  // the forward pass's predecessor of t
@@ -492,9 +495,12 @@ extern "C" int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, v
     auto k = ragged ? lstm_step_fwd_kernel<true> : lstm_step_fwd_kernel<false>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS) != hipSuccess)
         return GMT_ERR_HIP;
-    for (int step = 0; step < L; ++step)
-        hipLaunchKernelGGL(k, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), FWD_LDS, stream, (__bf16*)gates, c_all, (__bf16*)h_all,
-                           (__bf16*)h_drop, (const __bf16*)w_hh, lengths, L, B, H, ndir, step, n_mt, n_pt, drop_p, drop_seed);
+    const int ng = row_groups(B, FWD_TQ), g_mt = n_mt / ng;
+    const int rc = run_row_groups(ng, L, stream, [&](int g, int step, hipStream_t st) {
+        hipLaunchKernelGGL(k, dim3(ndir * g_mt * n_pt), dim3(NTHREADS), FWD_LDS, st, (__bf16*)gates, c_all, (__bf16*)h_all,
+                           (__bf16*)h_drop, (const __bf16*)w_hh, lengths, L, B, H, ndir, step, g * g_mt, g_mt, n_pt, drop_p, drop_seed);
+    });
+    if (rc != GMT_OK) return rc;
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }
@@ -516,10 +522,13 @@ extern "C" int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const vo
     constexpr int BWD_LDS = 64 * 1024;                         // the epilogue images; the mainloop's stages need 48-64 KiB
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS) != hipSuccess)
         return GMT_ERR_HIP;
-    for (int step = 0; step < L; ++step)
-        hipLaunchKernelGGL(k, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), BWD_LDS, stream, (__bf16*)gates, c_all,
+    const int ng = row_groups(B, small ? 64 : 128), g_mt = n_mt / ng;
+    const int rc = run_row_groups(ng, L, stream, [&](int g, int step, hipStream_t st) {
+        hipLaunchKernelGGL(k, dim3(ndir * g_mt * n_pt), dim3(NTHREADS), BWD_LDS, st, (__bf16*)gates, c_all,
                            (const __bf16*)dh_out, dh_fin, dc_carry, dh_carry, (const __bf16*)w_hhT, lengths, L, B, H, ndir, step,
-                           n_mt, n_pt, drop_p, drop_seed);
+                           g * g_mt, g_mt, n_pt, drop_p, drop_seed);
+    });
+    if (rc != GMT_OK) return rc;
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }
@@ -556,5 +565,12 @@ extern "C" int gmt_bf16_lstm_layer_bwd2(const void* pre_hat, const void* gates, 
                            (const __bf16*)pre_hat, (const __bf16*)gates, c_all, dct_all, dht_all, (__bf16*)hhat_all, hhat_fin,
                            g_gates, g_c, chat_carry, (const __bf16*)w_hh, L, B, H, ndir, step, n_mt, n_pt);
     GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+extern "C" int gmt_bf16_set_row_groups(int n)
+{
+    if (n < 1 || n > MAX_GROUPS) return GMT_ERR_BAD_ARG;
+    row_groups_setting().store(n);
     return GMT_OK;
 }

@@ -1,0 +1,79 @@
+#pragma once
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
+#include "gmt_common.h"
+
+namespace gmt_bf16 {
+
+// Row groups.  The rows of a batch are independent recurrences, so a layer call may run as NG independent chains of
+// step launches, each over B / NG rows, on streams of their own: the workgroups of ONE launch move in lock-step (all in
+// the contraction, then all in the HBM-heavy epilogue), two chains drift apart and one's epilogue runs under the other's
+// MFMAs; a chain's launch boundary is covered by the other chain as well.  The side streams are the library's own (one
+// set per device, created on first use), forked from and joined to the caller's stream with events, so the caller sees
+// an ordinary in-order call.
+constexpr int MAX_GROUPS = 4, MAX_DEVICES = 64;
+struct side_streams { hipStream_t s[MAX_GROUPS - 1]; hipEvent_t fork, join[MAX_GROUPS - 1]; bool ok; };
+
+inline side_streams* side_streams_of_device()
+{
+    static side_streams table[MAX_DEVICES] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    side_streams& e = table[dev];
+    if (!e.ok) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        for (int i = 0; i < MAX_GROUPS - 1; ++i) {
+            if (hipStreamCreateWithPriority(&e.s[i], hipStreamNonBlocking, hi) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&e.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        e.ok = true;
+    }
+    return &e;
+}
+
+// the wanted number of row groups: GMT_BF16_ROW_GROUPS (default 2), or what gmt_bf16_set_row_groups last set
+inline std::atomic<int>& row_groups_setting()
+{
+    static std::atomic<int> want([] {
+        const char* v = getenv("GMT_BF16_ROW_GROUPS");
+        const int n = v ? atoi(v) : 2;
+        return n < 1 ? 1 : (n > MAX_GROUPS ? MAX_GROUPS : n);
+    }());
+    return want;
+}
+
+// number of row groups for a layer call over B rows: every group keeps its `tile_rows`-row tiles in fours (XCD patches)
+inline int row_groups(int B, int tile_rows)
+{
+    int ng = row_groups_setting().load();
+    while (ng > 1 && (B % (ng * 4 * tile_rows) != 0)) --ng;
+    return ng;
+}
+
+// runs launch(group, stream) for every step of every group: group 0 on the caller's stream, the others on side streams
+template <class F>
+int run_row_groups(int ng, int L, hipStream_t stream, F launch)
+{
+    side_streams* ss = ng > 1 ? side_streams_of_device() : nullptr;
+    if (ng > 1 && !ss) return GMT_ERR_HIP;
+    if (ng > 1) {
+        if (hipEventRecord(ss->fork, stream) != hipSuccess) return GMT_ERR_HIP;
+        for (int g = 1; g < ng; ++g)
+            if (hipStreamWaitEvent(ss->s[g - 1], ss->fork, 0) != hipSuccess) return GMT_ERR_HIP;
+    }
+    for (int step = 0; step < L; ++step)
+        for (int g = 0; g < ng; ++g) launch(g, step, g == 0 ? stream : ss->s[g - 1]);
+    for (int g = 1; g < ng; ++g) {
+        if (hipEventRecord(ss->join[g - 1], ss->s[g - 1]) != hipSuccess) return GMT_ERR_HIP;
+        if (hipStreamWaitEvent(stream, ss->join[g - 1], 0) != hipSuccess) return GMT_ERR_HIP;
+    }
+    return GMT_OK;
+}
+
+
+}  // namespace gmt_bf16

@@ -39,7 +39,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define GMT_ERR_WORKSPACE (-4)    /* caller's workspace is too small                     */
 
 /* ABI version of this header; gmt_version() of the loaded library must match. */
-#define GMT_ABI_VERSION 6
+#define GMT_ABI_VERSION 7
 int gmt_version(void);
 
 /* ---- kinematic features, "mode A" ---------------------------------------------------
@@ -360,6 +360,16 @@ int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, void* h_drop
 int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const void* dh_out, const float* dh_fin, float* dc_carry,
                             float* dh_carry, const void* w_hhT, const int* lengths, int ragged, int L, int B, int H,
                             int ndir, float drop_p, unsigned int drop_seed, hipStream_t stream);
+
+/* Row groups (no counterpart in the reference: a scheduling knob of this library).  The rows of a batch are independent
+ * recurrences, so gmt_bf16_lstm_layer_fwd / _bwd and gmt_bf16_gen_rollout_fwd / _bwd run a call as n independent chains of step
+ * launches over B / n rows each - chain 0 on the caller's stream, the others on streams the library owns (one set per device,
+ * created on first use), forked from and joined to the caller's stream by events, so the call stays in order for the caller.
+ * The workgroups of one launch move in lock-step (contraction, then the HBM-heavy epilogue); two chains overlap one's
+ * epilogue and launch boundary with the other's MFMAs.  Results do not depend on n.  n in 1..4 (default 2, or the
+ * environment's GMT_BF16_ROW_GROUPS); a call falls back to fewer groups when B / n is not a multiple of four row tiles.
+ * With n > 1 these calls must not be made under HIP stream capture of a single stream without cross-stream capture. */
+int gmt_bf16_set_row_groups(int n);
 
 /* Gradient penalty at this width (compute_gradient_penalty, RG.py:790-842; full-length batches only).
  * gmt_bf16_lstm_layer_bwd_gp: the backward sweep out of place (gates is kept, dA [L][B][ndir*4H] bf16 is written), which can also

@@ -472,3 +472,60 @@ def test_bf16_train_steps_vs_fp64_oracle():
         for k, v in ref.items():
             bar = 1.5e-1 if k == 'd_gp' else 5e-2
             assert abs(got[k] - v) <= bar * abs(v) + 5e-3, (k, got[k], v)
+
+
+def test_bf16_row_groups_do_not_change_results():
+    """gmt_bf16_set_row_groups (include/gmt_hip.h): the critic's layer sweeps and the generator's rollout / BPTT run as 1, 2 or
+    4 independent chains of step launches over disjoint row ranges on the library's own streams.  Same arithmetic per row, so
+    scores, outputs and every gradient must be BIT-identical to the single-chain run (1 024 ragged rows, H = 512, with both
+    dropout masks on; 4 groups fall back to 2 where 256 rows are not four tiles)."""
+    import generative_mouse_trajectories_amd as gmt
+    L_ = _L()
+    over = dict(latent_dim=16, generator_hidden_dim=512, discriminator_hidden_dim=512)
+    cfg = gmt.Config()
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    cfg.compute_dtype = 'bf16'
+    cfg.head_dropout = 0.0
+    torch.manual_seed(7)
+    D = gmt.Discriminator(cfg).to(DEV).train()
+    G = gmt.Generator(cfg).to(DEV).train()
+    Bs, T = 1024, 6
+    rng = np.random.default_rng(8)
+    lengths = rng.integers(T // 2, T + 1, Bs); lengths[:2] = T
+    b = H.batch_t(Bs, T, 9, lengths.tolist(), torch.float32)
+    traj = gmt.trajectory_to_absolute(b['starts'], b['sequences'][:, :, :2]).to(DEV)
+    dts = (torch.nn.functional.pad(b['sequences'][:, :, 2], (1, 0), value=0.001) * 50.0).to(DEV)
+    lp1 = (b['lengths'] + 1).to(DEV)
+    z = torch.randn(Bs, 16, generator=torch.Generator().manual_seed(10)).to(DEV)
+    R = torch.randn(Bs, T, 3, generator=torch.Generator().manual_seed(11)).to(DEV)
+    tf = [True, False, False, True, False, False]
+
+    state = {k: v.clone() for k, v in D.state_dict().items()}   # a training-mode forward advances the spectral-norm vectors
+
+    def run():
+        D.load_state_dict(state)
+        D.zero_grad(set_to_none=True); G.zero_grad(set_to_none=True)
+        tg = traj.clone().requires_grad_(True)
+        s = D(tg, dts, lp1, dropout_seed=31)
+        s.sum().backward()
+        out, _ = G(b['starts'].to(DEV), b['ends'].to(DEV), z, b['sequences'].to(DEV), tf_mask=tf, dropout_seed=32)
+        (out * R).sum().backward()
+        res = {'scores': s.detach().clone(), 'd/d positions': tg.grad.clone(), 'rollout': out.detach().clone()}
+        res.update({'D.' + k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None})
+        res.update({'G.' + k: p.grad.clone() for k, p in G.named_parameters() if p.grad is not None})
+        return res
+
+    try:
+        L_.call('gmt_bf16_set_row_groups', 1)
+        one = run()
+        for n in (2, 4):
+            L_.call('gmt_bf16_set_row_groups', n)
+            many = run()
+            assert many.keys() == one.keys()
+            for k in one:
+                assert torch.equal(one[k], many[k]), (n, k, H.relerr(many[k].cpu(), one[k].cpu()))
+    finally:
+        L_.call('gmt_bf16_set_row_groups', 2)
+    with pytest.raises(Exception):
+        L_.call('gmt_bf16_set_row_groups', 9)
