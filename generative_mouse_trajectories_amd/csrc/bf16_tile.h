@@ -26,6 +26,16 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Phase timing for the scratch/phase_bf16.hip experiment (compiled out of the library): thread 0 of every workgroup stamps
+// the wall clock at numbered points of a kernel.
+#ifdef GMT_PHASE_TIMING
+__device__ long long gmt_phase_buf[4096 * 16], gmt_phase_cyc[4096 * 16];
+#define GMT_PHASE(n) do { if (threadIdx.x == 0 && blockIdx.x < 4096) { gmt_phase_buf[blockIdx.x * 16 + (n)] = wall_clock64(); \
+                                                                       gmt_phase_cyc[blockIdx.x * 16 + (n)] = clock64(); } } while (0)
+#else
+#define GMT_PHASE(n) do { } while (0)
+#endif
+
 namespace gmt_bf16 {
 
 constexpr int BK = 64;                              // k per LDS stage: one 128-byte row per operand row
@@ -164,6 +174,111 @@ __device__ __forceinline__ void mainloop32(const __bf16* __restrict__ Pg, long l
     }
 }
 
+// The contraction for the per-timestep kernels: a ring of three LDS slots.  While K-tile t is consumed, tile t+1 is landing
+// and the DMA pieces of tile t+2 are issued - a few after each k-step's MFMAs, not in one burst: a CU's vector-memory path
+// takes an LDS-DMA piece (1 KiB) every ~25 cycles at best (scratch/dma_rate.hip: 48 KiB in 0.45-0.5 us with 8 waves issuing,
+// 0.7 with 4), about as long as the tile's MFMAs, and a wave that issues into a full queue is held until its piece is
+// taken; a burst after the barrier therefore parks every wave while the matrix pipe idles, then the pipe runs while the
+// memory path idles (measured: tile time = DMA time + MFMA time).  Spread, the two overlap.  The wait for a tile is a
+// COUNTED s_waitcnt (the pieces of the tile after it stay in flight) and the barrier the raw s_barrier (__syncthreads()
+// would drain vmcnt to 0).  Fragment reads run one k-step ahead of their MFMAs, across the tile boundary too: the barrier
+// for tile t+1 sits before the LAST k-step's MFMAs of tile t, when every wave holds all its fragments of tile t.
+// RBK = 32 or 64 (k per slot); 2 x 2 waves or 2 x 4 (NWQ = 4: two waves per SIMD); tile (64 NPB) x (32 NQB NWQ);
+// lds: 3 * (64 NPB + 32 NQB NWQ) * RBK * 2 bytes.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int NPB, int NQB, int RBK, int NST, int NWQ = 2>
+__device__ __forceinline__ void mainloop_ring(const __bf16* __restrict__ Pg, long long ldp, const __bf16* __restrict__ Qg,
+                                              long long ldq, int nk, char* lds, f32x16 (&acc)[NPB][NQB], int wave, int lane)
+{
+    static_assert(RBK == 32 || RBK == 64, "k per slot");
+    static_assert(NST == 3, "three slots: consumed, landing, being issued");
+    static_assert(NWQ == 2 || (NWQ == 4 && RBK == 64), "2 x 2 waves, or 2 x 4 (two per SIMD) with 64-deep slots");
+    constexpr int NWV = 2 * NWQ;
+    constexpr int TPr = 64 * NPB, TQr = 32 * NQB * NWQ, ROWB = RBK * 2, STG = (TPr + TQr) * ROWB, KS = RBK / 16;
+    constexpr int RPP = 1024 / ROWB * NWV;                       // rows per round of pieces (one piece per wave)
+    constexpr int PP = TPr / RPP, LPT = (TPr + TQr) / RPP;       // pieces per thread: of P, in all
+    static_assert(TPr % RPP == 0 && TQr % RPP == 0 && LPT < 32, "piece counts");
+    if (nk <= 0) return;
+    const int wp = wave / NWQ, wq = wave % NWQ;
+    const int lo = lane & 31, hi = lane >> 5;
+    // piece p of K-tile t -> slot: rows [p RPP + wave (RPP / NWV), + RPP / NWV) of P (p < PP) or Q
+    auto piece = [&](int t, int slot, int p) {
+        const bool isq = p >= PP;
+        const int j = isq ? p - PP : p;
+        const int lrow = lane / (ROWB / 16), pos = lane % (ROWB / 16);
+        const int row = j * RPP + wave * (RPP / NWV) + lrow;
+        const int chunk = RBK == 32 ? gmt_bf16_maps::stage32_src_chunk(row, pos) : gmt_bf16_maps::stage_src_chunk(row, pos);
+        const __bf16* src = (isq ? Qg + (long long)row * ldq : Pg + (long long)row * ldp) + (long long)t * RBK + chunk * 8;
+        char* dst = lds + slot * STG + (isq ? TPr * ROWB : 0) + (j * RPP + wave * (RPP / NWV)) * ROWB;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    bf16x8 pf[2][NPB], qf[2][NQB];
+    auto read_frags = [&](int slot, int ks, int set) {
+        const char* cur = lds + slot * STG;
+        const char* pt = cur + (wp * (TPr / 2) + lo) * ROWB;
+        const char* qt = cur + TPr * ROWB + (wq * (32 * NQB) + lo) * ROWB;
+        int off;
+        if constexpr (RBK == 32) off = gmt_bf16_maps::stage32_addr(lo, 2 * ks + hi) - lo * 64;
+        else off = gmt_bf16_maps::stage_addr(lo, 2 * ks + hi) - lo * 128;
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) pf[set][i] = *reinterpret_cast<const bf16x8*>(pt + i * 32 * ROWB + off);
+#pragma unroll
+        for (int j = 0; j < NQB; ++j) qf[set][j] = *reinterpret_cast<const bf16x8*>(qt + j * 32 * ROWB + off);
+    };
+#pragma unroll
+    for (int p = 0; p < LPT; ++p) piece(0, 0, p);
+    if (nk > 1) {
+#pragma unroll
+        for (int p = 0; p < LPT; ++p) piece(1, 1, p);
+        wait_vmcnt<LPT>();                                       // tile 0 has landed (this wave's pieces) ...
+    } else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                                // ... everybody's
+    read_frags(0, 0, 0);
+    int slot = 0;
+    for (int t = 0; t < nk; ++t) {
+        const int nslot = slot == 2 ? 0 : slot + 1, fslot = nslot == 2 ? 0 : nslot + 1;   // slots of tiles t+1, t+2
+        const bool fill = t + 2 < nk;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) read_frags(slot, ks + 1, (ks + 1) & 1);
+            else if (t + 1 < nk) {
+                // tile t+1 has landed: only the pieces of tile t+2 issued so far may still be in flight
+                if (fill) wait_vmcnt<(KS - 1) * LPT / KS>(); else wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave holds all its fragments of tile t
+                __builtin_amdgcn_s_barrier();
+                read_frags(nslot, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+#pragma unroll
+                for (int j = 0; j < NQB; ++j)
+                {
+#ifndef GMT_RING_NO_MFMA
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[ks & 1][i], qf[ks & 1][j], acc[i][j], 0, 0, 0);
+#else
+                    asm volatile("" :: "v"(pf[ks & 1][i]), "v"(qf[ks & 1][j]));
+#endif
+                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (fill) {                                          // this k-step's share of tile t+2 (slot of tile t-1: free since the last barrier)
+#pragma unroll
+                for (int p = ks * LPT / KS; p < (ks + 1) * LPT / KS; ++p) {
+#ifndef GMT_RING_NO_DMA                                       // (scratch experiments: the loop without its DMA / its MFMAs / its reads)
+                    piece(t + 2, fslot, p);
+#endif
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot = nslot;
+    }
+}
+
 template <int NPB, int NQB>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NPB][NQB])
 {
@@ -198,8 +313,8 @@ template <int ROWB> struct RowImage {
     // 16-byte chunk `chunk` (identity * 16 for a contiguous row); nrows % (4 RPI) == 0
     template <class RowMap, class ColMap>
     static __device__ __forceinline__ void dma_in(const char* __restrict__ g, long long ld_bytes, char* lds, int nrows,
-                                                  RowMap rowmap, ColMap colmap, int wave, int lane) {
-        for (int inst = wave; inst < nrows / RPI; inst += 4) {
+                                                  RowMap rowmap, ColMap colmap, int wave, int lane, int nwaves = 4) {
+        for (int inst = wave; inst < nrows / RPI; inst += nwaves) {
             const int row = inst * RPI + lane / CH;
             const int chunk = gmt_bf16_maps::image_src_chunk(ROWB, row, lane);
             const char* src = g + (long long)rowmap(row) * ld_bytes + colmap(chunk);
@@ -209,8 +324,8 @@ template <int ROWB> struct RowImage {
     }
     template <class RowMap, class ColMap>
     static __device__ __forceinline__ void copy_out(char* __restrict__ g, long long ld_bytes, const char* lds, int nrows,
-                                                    RowMap rowmap, ColMap colmap, int wave, int lane) {
-        for (int inst = wave; inst < nrows / RPI; inst += 4) {
+                                                    RowMap rowmap, ColMap colmap, int wave, int lane, int nwaves = 4) {
+        for (int inst = wave; inst < nrows / RPI; inst += nwaves) {
             const int row = inst * RPI + lane / CH;
             const int chunk = gmt_bf16_maps::image_src_chunk(ROWB, row, lane);
             const f32x4 v = *reinterpret_cast<const f32x4*>(lds + inst * 1024 + lane * 16);
@@ -219,13 +334,13 @@ template <int ROWB> struct RowImage {
     }
     template <class RowMap>
     static __device__ __forceinline__ void dma_in(const char* __restrict__ g, long long ld_bytes, char* lds, int nrows,
-                                                  RowMap rowmap, int wave, int lane) {
-        dma_in(g, ld_bytes, lds, nrows, rowmap, [](int c) { return c * 16; }, wave, lane);
+                                                  RowMap rowmap, int wave, int lane, int nwaves = 4) {
+        dma_in(g, ld_bytes, lds, nrows, rowmap, [](int c) { return c * 16; }, wave, lane, nwaves);
     }
     template <class RowMap>
     static __device__ __forceinline__ void copy_out(char* __restrict__ g, long long ld_bytes, const char* lds, int nrows,
-                                                    RowMap rowmap, int wave, int lane) {
-        copy_out(g, ld_bytes, lds, nrows, rowmap, [](int c) { return c * 16; }, wave, lane);
+                                                    RowMap rowmap, int wave, int lane, int nwaves = 4) {
+        copy_out(g, ld_bytes, lds, nrows, rowmap, [](int c) { return c * 16; }, wave, lane, nwaves);
     }
 };
 

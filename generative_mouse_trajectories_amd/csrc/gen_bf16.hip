@@ -18,13 +18,20 @@ namespace {
 
 using namespace gmt_bf16;
 
-constexpr int G_TQ = 128;                                      // rows per workgroup (two workgroups per CU)
-constexpr int G_PRE_OFF = 0, G_C_OFF = 64 * 512, G_H_OFF = G_C_OFF + 64 * 256, G_HD_OFF = G_H_OFF + 64 * 128;
-constexpr int G_LDS = G_HD_OFF + 64 * 128;                     // 64 KiB
+constexpr int G_TQ = 128;                                      // rows per workgroup of the cell kernels
+constexpr int G_NST = 3, G_BK = 64;                            // ring slots of the contractions; k per slot
+constexpr int G_LDS = G_NST * (256 + 128) * G_BK * 2;          // 144 KiB: one workgroup per CU
+// the cell kernel's epilogue images, all 128 rows at once: pre-activations / gates [128][512 B], c [128][256 B], h, dropped h
+constexpr int G_PRE_OFF = 0, G_C_OFF = 128 * 512, G_H_OFF = G_C_OFF + 128 * 256, G_HD_OFF = G_H_OFF + 128 * 128;
+static_assert(G_HD_OFF + 128 * 128 <= G_LDS, "epilogue images");
+constexpr int G_CELL_THREADS = 512;                            // 8 waves = 2 (gate slabs) x 4 (32-row groups): two per SIMD
 
 // One LSTM layer step over all rows.  X: [B][ldx] bf16 (K = 32 nk32 columns used); W: [4H slab order][32 nk32] bf16.
 // pre: [B][4H] bf16 plane (slab order) or NULL (then bias[4H]); c_prev -> c_out [B][H] fp32; h -> h0 (and h1 if given).
-__global__ __launch_bounds__(NTHREADS, 2)
+// The contraction is bounded by what a CU's vector-memory path delivers to the LDS (64 B/clk: 48 KiB per 64-deep K-tile
+// against 1 024 cycles of MFMAs) and an LDS-DMA instruction holds its wave's issue for 60-180 cycles, so the tile is worked
+// by two waves per SIMD: one wave's DMA issue and fragment waits run under the other's MFMAs.
+__global__ __launch_bounds__(G_CELL_THREADS)
 void gen_cell_kernel(const __bf16* __restrict__ W, const __bf16* __restrict__ X, long long ldx, int nk32,
                      const __bf16* __restrict__ pre, const float* __restrict__ bias,
                      const float* __restrict__ c_prev, float* __restrict__ c_out,
@@ -39,15 +46,17 @@ void gen_cell_kernel(const __bf16* __restrict__ W, const __bf16* __restrict__ X,
     const long long row0 = (long long)(mt0 + mt) * G_TQ;         // this launch covers row tiles [mt0, mt0 + n_mt)
     const long long K = 32LL * nk32;
 
-    f32x16 acc[4][2];
-    zero_acc<4, 2>(acc);
-    mainloop32<4, 2>(W + (long long)pt * TP * K, K, X + row0 * ldx, ldx, nk32, lds, acc, wave, lane);
+    f32x16 acc[4][1];
+    zero_acc<4, 1>(acc);
+    GMT_PHASE(0);
+    mainloop_ring<4, 1, G_BK, G_NST, 4>(W + (long long)pt * TP * K, K, X + row0 * ldx, ldx, nk32 * 32 / G_BK, lds, acc, wave, lane);
+    GMT_PHASE(1);
 
-    const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
+    const int wp = wave >> 2, wq = wave & 3, lo = lane & 31, hi = lane >> 5;
     using GI = RowImage<512>;
     using CI = RowImage<256>;
     using HI = RowImage<128>;
-    const int rl = wq * 32 + lo;
+    const int rl = wq * 32 + lo;                                 // this lane's row within the tile (= image row)
     const char* Pt = pre ? (const char*)(pre + row0 * 4 * H + pt * TP) : nullptr;
     const char* Cp = (const char*)(c_prev + row0 * H + pt * (TP / 4));
     char* Co = (char*)(c_out + row0 * H + pt * (TP / 4));
@@ -56,61 +65,65 @@ void gen_cell_kernel(const __bf16* __restrict__ W, const __bf16* __restrict__ X,
     // keep(seed, (t*B + row)*H + unit) - ops.dropout_keep_mask(T, B, H, p, seed) replays it; the recurrent copy (h0) does not
     const uint32_t thresh24 = (uint32_t)(drop_p * 16777216.0f);
     const float keep_scale = 1.0f / (1.0f - drop_p);
+    auto rowmap = [](int r) { return r; };
+    __syncthreads();                                             // the ring's last tile is read by everybody
+    if (Pt) GI::dma_in(Pt, 4LL * H * 2, lds + G_PRE_OFF, 128, rowmap, wave, lane, 8);
+    CI::dma_in(Cp, (long long)H * 4, lds + G_C_OFF, 128, rowmap, wave, lane, 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    GMT_PHASE(2);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        auto rowmap = [j](int r) { return (r >> 5) * 64 + j * 32 + (r & 31); };
-        __syncthreads();
-        if (Pt) GI::dma_in(Pt, 4LL * H * 2, lds + G_PRE_OFF, 64, rowmap, wave, lane);
-        CI::dma_in(Cp, (long long)H * 4, lds + G_C_OFF, 64, rowmap, wave, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const int ucol = wp * 32 + 8 * g4 + 4 * hi;
+        float a[4][4];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int ucol = wp * 32 + 8 * g4 + 4 * hi;
-            float a[4][4];
+        for (int g = 0; g < 4; ++g) {
+            if (Pt) {
+                const bf16x4 p = *reinterpret_cast<const bf16x4*>(lds + G_PRE_OFF + GI::addr(rl, (wp * 128 + g * 32 + 8 * g4 + 4 * hi) * 2));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (Pt) {
-                    const bf16x4 p = *reinterpret_cast<const bf16x4*>(lds + G_PRE_OFF + GI::addr(rl, (wp * 128 + g * 32 + 8 * g4 + 4 * hi) * 2));
+                for (int e = 0; e < 4; ++e) a[g][e] = acc[g][0][4 * g4 + e] + (float)p[e];
+            } else {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bias + pt * TP + wp * 128 + g * 32 + 8 * g4 + 4 * hi);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[g][e] = acc[g][j][4 * g4 + e] + (float)p[e];
-                } else {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + pt * TP + wp * 128 + g * 32 + 8 * g4 + 4 * hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a[g][e] = acc[g][j][4 * g4 + e] + b[e];
-                }
-            }
-            const f32x4 cp = *reinterpret_cast<const f32x4*>(lds + G_C_OFF + CI::addr(rl, ucol * 4));
-            f32x4 cn;
-            float hn[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a[0][e] = gmt_sigmoid(a[0][e]); a[1][e] = gmt_sigmoid(a[1][e]);
-                a[2][e] = gmt_tanh(a[2][e]);    a[3][e] = gmt_sigmoid(a[3][e]);
-                cn[e] = a[1][e] * cp[e] + a[0][e] * a[2][e];
-                hn[e] = a[3][e] * gmt_tanh(cn[e]);
-            }
-            if (Go) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<bf16x4*>(lds + G_PRE_OFF + GI::addr(rl, (wp * 128 + g * 32 + 8 * g4 + 4 * hi) * 2)) =
-                        pack4(a[g][0], a[g][1], a[g][2], a[g][3]);
-            }
-            *reinterpret_cast<f32x4*>(lds + G_C_OFF + CI::addr(rl, ucol * 4)) = cn;
-            *reinterpret_cast<bf16x4*>(lds + G_H_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
-            if (h1 && thresh24) {
-                const uint32_t idx = (uint32_t)((drop_row0 + row0 + wq * 64 + j * 32 + lo) * H + pt * (TP / 4) + ucol);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hn[e] = gmt_keep(idx + e, drop_seed, thresh24) ? hn[e] * keep_scale : 0.f;
-                *reinterpret_cast<bf16x4*>(lds + G_HD_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
+                for (int e = 0; e < 4; ++e) a[g][e] = acc[g][0][4 * g4 + e] + b[e];
             }
         }
-        __syncthreads();
-        CI::copy_out(Co, (long long)H * 4, lds + G_C_OFF, 64, rowmap, wave, lane);
-        if (Go) GI::copy_out(Go, 4LL * H * 2, lds + G_PRE_OFF, 64, rowmap, wave, lane);
-        HI::copy_out((char*)(h0 + row0 * ldh0 + pt * (TP / 4)), ldh0 * 2, lds + G_H_OFF, 64, rowmap, wave, lane);
-        if (h1) HI::copy_out((char*)(h1 + row0 * ldh1 + pt * (TP / 4)), ldh1 * 2, lds + (thresh24 ? G_HD_OFF : G_H_OFF), 64, rowmap, wave, lane);
+        const f32x4 cp = *reinterpret_cast<const f32x4*>(lds + G_C_OFF + CI::addr(rl, ucol * 4));
+        f32x4 cn;
+        float hn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[0][e] = gmt_sigmoid(a[0][e]); a[1][e] = gmt_sigmoid(a[1][e]);
+            a[2][e] = gmt_tanh(a[2][e]);    a[3][e] = gmt_sigmoid(a[3][e]);
+            cn[e] = a[1][e] * cp[e] + a[0][e] * a[2][e];
+            hn[e] = a[3][e] * gmt_tanh(cn[e]);
+        }
+        if (Go) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<bf16x4*>(lds + G_PRE_OFF + GI::addr(rl, (wp * 128 + g * 32 + 8 * g4 + 4 * hi) * 2)) =
+                    pack4(a[g][0], a[g][1], a[g][2], a[g][3]);
+        }
+        *reinterpret_cast<f32x4*>(lds + G_C_OFF + CI::addr(rl, ucol * 4)) = cn;
+        *reinterpret_cast<bf16x4*>(lds + G_H_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
+        if (h1 && thresh24) {
+            const uint32_t idx = (uint32_t)((drop_row0 + row0 + rl) * H + pt * (TP / 4) + ucol);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hn[e] = gmt_keep(idx + e, drop_seed, thresh24) ? hn[e] * keep_scale : 0.f;
+            *reinterpret_cast<bf16x4*>(lds + G_HD_OFF + HI::addr(rl, ucol * 2)) = pack4(hn[0], hn[1], hn[2], hn[3]);
+        }
     }
+    __syncthreads();
+    GMT_PHASE(3);
+    CI::copy_out(Co, (long long)H * 4, lds + G_C_OFF, 128, rowmap, wave, lane, 8);
+    if (Go) GI::copy_out(Go, 4LL * H * 2, lds + G_PRE_OFF, 128, rowmap, wave, lane, 8);
+    HI::copy_out((char*)(h0 + row0 * ldh0 + pt * (TP / 4)), ldh0 * 2, lds + G_H_OFF, 128, rowmap, wave, lane, 8);
+    if (h1) HI::copy_out((char*)(h1 + row0 * ldh1 + pt * (TP / 4)), ldh1 * 2, lds + (thresh24 ? G_HD_OFF : G_H_OFF), 128, rowmap, wave, lane, 8);
+    GMT_PHASE(4);
+#ifdef GMT_PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GMT_PHASE(5);
+#endif
 }
 
 // Head + step bookkeeping.  HH = H/2 must be 256 (one weight tile): the three outputs of a row are sums over all HH units.
@@ -124,33 +137,47 @@ struct head_args {
     int t, B, H, blk0;                               // blk0: first row tile of this launch (row groups)
 };
 
-__global__ __launch_bounds__(NTHREADS, 2)
+// NQB = 1: 64-row tiles (B / 64 workgroups - the launch is small, so the smaller tile is what spreads it over the chip);
+// NQB = 2: 128-row tiles for batches that fill the chip either way.  One workgroup per CU (the ring takes the LDS), so the
+// epilogue may use the whole register file.
+template <int NQB>
+__global__ __launch_bounds__(NTHREADS)
 void gen_head_kernel(head_args a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int TQr = 64 * NQB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long row0 = (long long)(a.blk0 + blockIdx.x) * G_TQ;
+    const long long row0 = (long long)(a.blk0 + blockIdx.x) * TQr;
     const int HH = a.H / 2;
 
-    f32x16 acc[4][2];
-    zero_acc<4, 2>(acc);
-    mainloop32<4, 2>(a.wh1, a.H, a.h + row0 * a.ldh, a.ldh, a.H / 32, lds, acc, wave, lane);
+    f32x16 acc[4][NQB];
+    zero_acc<4, NQB>(acc);
+    GMT_PHASE(10);
+    mainloop_ring<4, NQB, G_BK, G_NST>(a.wh1, a.H, a.h + row0 * a.ldh, a.ldh, a.H / G_BK, lds, acc, wave, lane);
+    GMT_PHASE(11);
     __syncthreads();
     float* w2s = reinterpret_cast<float*>(lds);               // [3][HH]
-    float* red = w2s + 3 * 256;                               // [2][128][4]
+    float* bs = w2s + 3 * 256;                                // [HH]
+    float* red = bs + 256;                                    // [2][TQr][4]
     for (int i = threadIdx.x; i < 3 * HH; i += NTHREADS) w2s[i] = a.wh2[i];
+    for (int i = threadIdx.x; i < HH; i += NTHREADS) bs[i] = a.bh1[i];
     __syncthreads();
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
+    float o[NQB][3];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        float o[3] = {0.f, 0.f, 0.f};
+    for (int j = 0; j < NQB; ++j) o[j][0] = o[j][1] = o[j][2] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int u = wp * 128 + i * 32 + 8 * g4 + 4 * hi;
-                const f32x4 b = *reinterpret_cast<const f32x4*>(a.bh1 + u);
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int u = wp * 128 + i * 32 + 8 * g4 + 4 * hi;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bs + u);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(w2s + u);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(w2s + HH + u);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(w2s + 2 * HH + u);
+#pragma unroll
+            for (int j = 0; j < NQB; ++j) {
                 float y[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -158,27 +185,29 @@ void gen_head_kernel(head_args a)
                     y[e] = v > 0.f ? v : 0.2f * v;
                 }
                 if (a.y_out)
-                    *reinterpret_cast<bf16x4*>(a.y_out + (row0 + wq * 64 + j * 32 + lo) * HH + u) = pack4(y[0], y[1], y[2], y[3]);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(w2s + k * HH + u);
-                    o[k] += y[0] * w[0] + y[1] * w[1] + y[2] * w[2] + y[3] * w[3];
-                }
+                    *reinterpret_cast<bf16x4*>(a.y_out + (row0 + wq * (32 * NQB) + j * 32 + lo) * HH + u) = pack4(y[0], y[1], y[2], y[3]);
+                o[j][0] += y[0] * w0[0] + y[1] * w0[1] + y[2] * w0[2] + y[3] * w0[3];
+                o[j][1] += y[0] * w1[0] + y[1] * w1[1] + y[2] * w1[2] + y[3] * w1[3];
+                o[j][2] += y[0] * w2[0] + y[1] * w2[1] + y[2] * w2[2] + y[3] * w2[3];
             }
+        }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) o[k] += __shfl_xor(o[k], 32, 64);
+    for (int j = 0; j < NQB; ++j) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[j][k] += __shfl_xor(o[j][k], 32, 64);
         if (hi == 0) {
-            float* r = red + ((wp * 128) + wq * 64 + j * 32 + lo) * 4;
-            r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+            float* r = red + (wp * TQr + wq * (32 * NQB) + j * 32 + lo) * 4;
+            r[0] = o[j][0]; r[1] = o[j][1]; r[2] = o[j][2];
         }
     }
     __syncthreads();
-    if (threadIdx.x < G_TQ) {
+    GMT_PHASE(12);
+    if (threadIdx.x < TQr) {
         const int rr = threadIdx.x;
         const long long row = row0 + rr;
-        const float o0 = red[rr * 4 + 0] + red[(128 + rr) * 4 + 0] + a.bh2[0];
-        const float o1 = red[rr * 4 + 1] + red[(128 + rr) * 4 + 1] + a.bh2[1];
-        const float o2 = red[rr * 4 + 2] + red[(128 + rr) * 4 + 2] + a.bh2[2];
+        const float o0 = red[rr * 4 + 0] + red[(TQr + rr) * 4 + 0] + a.bh2[0];
+        const float o1 = red[rr * 4 + 1] + red[(TQr + rr) * 4 + 1] + a.bh2[1];
+        const float o2 = red[rr * 4 + 2] + red[(TQr + rr) * 4 + 2] + a.bh2[2];
         const float dt = (o2 > 20.f ? o2 : log1pf(expf(o2))) + 0.001f;                 // F.softplus, RG.py:577-580
         float* os = a.out_seq + ((long long)a.t * a.B + row) * 3;
         os[0] = o0; os[1] = o1; os[2] = dt;
@@ -202,6 +231,7 @@ void gen_head_kernel(head_args a)
             un[7 + s] = (__bf16)(u[s] - (float)h);
         }
     }
+    GMT_PHASE(13);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -214,7 +244,15 @@ void gen_head_kernel(head_args a)
 // row-steps afterwards (gmt_bf16_wgrad_tn against the saved operands x0 / x1).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int GB_G_OFF = 0, GB_C_OFF = 64 * 512, GB_CP_OFF = GB_C_OFF + 64 * 256;          // as the critic's backward step
-constexpr int GB_LDS = 64 * 1024;
+constexpr int GB_LDS = 72 * 1024;                              // >= the contraction's ring (3 x 24 KiB with 64-row tiles) and the epilogue images
+
+template <int NQB>
+__device__ __forceinline__ void gb_contract(const __bf16* __restrict__ Pg, long long ldp, const __bf16* __restrict__ Qg,
+                                            long long ldq, int K, char* lds, f32x16 (&acc)[2][NQB], int wave, int lane)
+{
+    if constexpr (NQB == 1) mainloop_ring<2, 1, 64, 3>(Pg, ldp, Qg, ldq, K / 64, lds, acc, wave, lane);
+    else mainloop_ring<2, 2, 32, 3>(Pg, ldp, Qg, ldq, K / 32, lds, acc, wave, lane);
+}
 
 template <int NQB>
 __global__ __launch_bounds__(NTHREADS, 2)
@@ -233,7 +271,7 @@ void gen_bwd_cell_kernel(const __bf16* __restrict__ P1, const __bf16* __restrict
     const long long row0 = (long long)(mt0 + mt) * T::TQ;
     f32x16 acc[2][NQB];
     zero_acc<2, NQB>(acc);
-    mainloop<2, NQB>(P1 + (long long)pt * T::TP * (nk1 * BK), (long long)nk1 * BK, Q1 + row0 * ldq1, ldq1, nk1, lds, acc, wave, lane);
+    gb_contract<NQB>(P1 + (long long)pt * T::TP * (nk1 * BK), (long long)nk1 * BK, Q1 + row0 * ldq1, ldq1, nk1 * BK, lds, acc, wave, lane);
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
     const uint32_t thresh24 = (uint32_t)(drop_p * 16777216.0f);
     if (thresh24) {
@@ -252,7 +290,7 @@ void gen_bwd_cell_kernel(const __bf16* __restrict__ P1, const __bf16* __restrict
     }
     if (nk2 > 0) {
         __syncthreads();                                        // the first contraction's last tile is read by everybody
-        mainloop<2, NQB>(P2 + (long long)pt * T::TP * (nk2 * BK), (long long)nk2 * BK, Q2 + row0 * ldq2, ldq2, nk2, lds, acc, wave, lane);
+        gb_contract<NQB>(P2 + (long long)pt * T::TP * (nk2 * BK), (long long)nk2 * BK, Q2 + row0 * ldq2, ldq2, nk2 * BK, lds, acc, wave, lane);
     }
     char* Gt = (char*)(gates + row0 * 4 * H + pt * 512);
     const char* Ct = (const char*)(c_t + row0 * H + pt * 128);
@@ -409,8 +447,11 @@ extern "C" int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* a, hipStream_t 
     const int H = a->H, B = a->B, K0 = H + 64, K1 = 2 * H;
     const long long ld0 = train ? GMT_BF16_GEN_X0_TRAIN_WIDTH : K0;
     const int n_mt = B / G_TQ, n_pt = 4 * H / TP;
+    const bool head_small = B / 128 < 512;                     // 64-row head tiles unless 128-row ones fill the chip twice over
+    auto head = head_small ? gen_head_kernel<1> : gen_head_kernel<2>;
+    const int head_lds = G_NST * (256 + (head_small ? 64 : 128)) * G_BK * 2;
     if (hipFuncSetAttribute((const void*)gen_cell_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gen_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess)
+        hipFuncSetAttribute((const void*)head, hipFuncAttributeMaxDynamicSharedMemorySize, head_lds) != hipSuccess)
         return GMT_ERR_HIP;
     __bf16* x0 = (__bf16*)a->x0; __bf16* x1 = (__bf16*)a->x1;
     const int ng = row_groups(B, G_TQ), g_mt = n_mt / ng;
@@ -422,11 +463,11 @@ extern "C" int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* a, hipStream_t 
         __bf16* g0 = train ? (__bf16*)a->gates0 + (size_t)t * B * 4 * H : nullptr;
         __bf16* g1 = train ? (__bf16*)a->gates1 + (size_t)t * B * 4 * H : nullptr;
         // layer 0: reads x0[cur] = [h0_{t-1} | u_t]; h0_t -> x0[nxt][:, :H] (next step's recurrence) and x1[cur][:, :H]
-        hipLaunchKernelGGL(gen_cell_kernel, dim3(g_mt * n_pt), dim3(NTHREADS), G_LDS, st, (const __bf16*)a->w0, x0c, ld0,
+        hipLaunchKernelGGL(gen_cell_kernel, dim3(g_mt * n_pt), dim3(G_CELL_THREADS), G_LDS, st, (const __bf16*)a->w0, x0c, ld0,
                            K0 / 32, (const __bf16*)a->cond_pre, (const float*)nullptr, a->c0 + cur * B * H,
                            a->c0 + nxt * B * H, x0n, ld0, x1c, (long long)K1, g0, H, g * g_mt, g_mt, n_pt, a->dropout_p, a->seed, (long long)t * B);
         // layer 1: reads x1[cur] = [h0_t | h1_{t-1}]; h1_t -> x1[nxt][:, H:]
-        hipLaunchKernelGGL(gen_cell_kernel, dim3(g_mt * n_pt), dim3(NTHREADS), G_LDS, st, (const __bf16*)a->w1, x1c, (long long)K1,
+        hipLaunchKernelGGL(gen_cell_kernel, dim3(g_mt * n_pt), dim3(G_CELL_THREADS), G_LDS, st, (const __bf16*)a->w1, x1c, (long long)K1,
                            K1 / 32, (const __bf16*)nullptr, a->bias1, a->c1 + cur * B * H, a->c1 + nxt * B * H,
                            x1n + H, (long long)K1, (__bf16*)nullptr, 0LL, g1, H, g * g_mt, g_mt, n_pt, 0.f, 0u, 0LL);
         head_args h;
@@ -437,8 +478,9 @@ extern "C" int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* a, hipStream_t 
         h.u_next = x0n + H; h.ldu = ld0;
         h.y_out = train ? (__bf16*)a->y_all + (size_t)t * B * (H / 2) : nullptr;
         h.oraw_out = train ? a->oraw_all + (size_t)t * B : nullptr;
-        h.t = t; h.B = B; h.H = H; h.blk0 = g * g_mt;
-        hipLaunchKernelGGL(gen_head_kernel, dim3(g_mt), dim3(NTHREADS), G_LDS, st, h);
+        const int hb = head_small ? 2 * g_mt : g_mt;            // head tiles per group
+        h.t = t; h.B = B; h.H = H; h.blk0 = g * hb;
+        hipLaunchKernelGGL(head, dim3(hb), dim3(NTHREADS), head_lds, st, h);
     });
     if (rc != GMT_OK) return rc;
     GMT_LAUNCH_CHECK();

@@ -30,7 +30,9 @@ using namespace gmt_bf16;
 // Epilogue images: pre-activations / gates [64][512 B], cell state [64][256 B], h [64][128 B], dropped h [64][128 B].
 constexpr int FWD_TQ = 128;
 constexpr int FWD_G_OFF = 0, FWD_C_OFF = 64 * 512, FWD_H_OFF = FWD_C_OFF + 64 * 256, FWD_HD_OFF = FWD_H_OFF + 64 * 128;
-constexpr int FWD_LDS = FWD_HD_OFF + 64 * 128;                 // 64 KiB (>= the mainloop's 2 x 24 KiB)
+constexpr int FWD_NST = 3;                                     // ring slots of the contraction: 3 x 24 KiB
+constexpr int FWD_LDS = FWD_NST * 24 * 1024;                   // 72 KiB (>= the epilogue's 64 KiB of images): two workgroups per CU
+static_assert(FWD_LDS >= FWD_HD_OFF + 64 * 128, "epilogue images");
 
 // keep-and-scale of 4 consecutive elements starting at idx (idx % 4 == 0) of the inter-layer dropout mask (RG.py:725): the
 // same function of (seed, element index in [L][B][ndir*H]) as the fp32 path's gmt_keep16, so ops.dropout_keep_mask replays it
@@ -72,7 +74,9 @@ void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf
 
     f32x16 acc[4][2];
     zero_acc<4, 2>(acc);
-    mainloop32<4, 2>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H, Hp, ldh, has_prev ? H / 32 : 0, lds, acc, wave, lane);
+    GMT_PHASE(0);
+    mainloop_ring<4, 2, 32, FWD_NST>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H, Hp, ldh, has_prev ? H / 32 : 0, lds, acc, wave, lane);
+    GMT_PHASE(1);
 
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
     using GI = RowImage<512>;
@@ -88,6 +92,7 @@ void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf
         if (has_prev) CI::dma_in(Cp, ldh * 4, lds + FWD_C_OFF, 64, rowmap, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        GMT_PHASE(2 + 4 * j);
         bool valid = true;
         if (RAGGED) valid = t < lengths[row0 + brow];
 #pragma unroll
@@ -138,10 +143,16 @@ void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf
             }
         }
         __syncthreads();
+        GMT_PHASE(3 + 4 * j);
         GI::copy_out(Gt, ldg * 2, lds + FWD_G_OFF, 64, rowmap, wave, lane);
         CI::copy_out(Ct, ldh * 4, lds + FWD_C_OFF, 64, rowmap, wave, lane);
         HI::copy_out(Ht, ldh * 2, lds + FWD_H_OFF, 64, rowmap, wave, lane);
         if (Hdt) HI::copy_out(Hdt, ldh * 2, lds + FWD_HD_OFF, 64, rowmap, wave, lane);
+        GMT_PHASE(4 + 4 * j);
+#ifdef GMT_PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GMT_PHASE(5 + 4 * j);
+#endif
     }
 }
 
@@ -150,6 +161,16 @@ void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf
 // (a "quarter": 64 rows x 2 slabs), with the saved gates - overwritten by d(pre-activation) - and the two cell-state
 // planes moving through LDS as whole rows; the carried dc (and the thin dh inputs) are read and written directly.
 constexpr int BWD_G_OFF = 0, BWD_C_OFF = 64 * 512, BWD_CP_OFF = BWD_C_OFF + 64 * 256;      // 32 + 16 + 16 KiB
+constexpr int BWD_LDS = 72 * 1024;                             // >= the contraction's ring (3 x 24 KiB with 64-row tiles) and the epilogue images
+
+// the backward steps' contraction over K columns: 128 units x 64 rows in 64-deep slots, x 128 rows in 32-deep ones
+template <int NQB>
+__device__ __forceinline__ void bwd_contract(const __bf16* __restrict__ Pg, long long ldp, const __bf16* __restrict__ Qg,
+                                             long long ldq, int K, char* lds, f32x16 (&acc)[2][NQB], int wave, int lane)
+{
+    if constexpr (NQB == 1) mainloop_ring<2, 1, 64, 3>(Pg, ldp, Qg, ldq, K / 64, lds, acc, wave, lane);
+    else mainloop_ring<2, 2, 32, 3>(Pg, ldp, Qg, ldq, K / 32, lds, acc, wave, lane);
+}
 
 template <bool RAGGED, int NQB>
 __global__ __launch_bounds__(NTHREADS, 2)
@@ -185,8 +206,8 @@ void lstm_step_bwd_kernel(__bf16* __restrict__ G, const float* __restrict__ Call
 
     f32x16 acc[2][NQB];
     zero_acc<2, NQB>(acc);
-    mainloop<2, NQB>(WhhT + ((long long)d * H + (long long)pt * T::TP) * 4 * H, 4LL * H, Gn, ldg, has_next ? 4 * H / BK : 0,
-                   lds, acc, wave, lane);
+    bwd_contract<NQB>(WhhT + ((long long)d * H + (long long)pt * T::TP) * 4 * H, 4LL * H, Gn, ldg, has_next ? 4 * H : 0,
+                      lds, acc, wave, lane);
 
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
     using GI = RowImage<512>;
@@ -410,7 +431,7 @@ void lstm_step_bwd2_kernel(const __bf16* __restrict__ PH, const __bf16* __restri
     const long long row0 = (long long)mt * FWD_TQ;
     f32x16 acc[4][2];
     zero_acc<4, 2>(acc);
-    mainloop32<4, 2>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H,
+    mainloop_ring<4, 2, 32, FWD_NST>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H,
                      hhat_all + ((long long)tprev * B + row0) * ldh + (long long)d * H, ldh, has_prev ? H / 32 : 0, lds, acc, wave, lane);
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -519,7 +540,6 @@ extern "C" int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const vo
     const int n_mt = B / (small ? 64 : 128);
     auto k = small ? (ragged ? lstm_step_bwd_kernel<true, 1> : lstm_step_bwd_kernel<false, 1>)
                    : (ragged ? lstm_step_bwd_kernel<true, 2> : lstm_step_bwd_kernel<false, 2>);
-    constexpr int BWD_LDS = 64 * 1024;                         // the epilogue images; the mainloop's stages need 48-64 KiB
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS) != hipSuccess)
         return GMT_ERR_HIP;
     const int ng = row_groups(B, small ? 64 : 128), g_mt = n_mt / ng;

@@ -12,26 +12,25 @@ namespace gmt_bf16 {
 // MFMAs; a chain's launch boundary is covered by the other chain as well.  The side streams are the library's own (one
 // set per device, created on first use), forked from and joined to the caller's stream with events, so the caller sees
 // an ordinary in-order call.
-constexpr int MAX_GROUPS = 4, MAX_DEVICES = 64;
-struct side_streams { hipStream_t s[MAX_GROUPS - 1]; hipEvent_t fork, join[MAX_GROUPS - 1]; bool ok; };
+constexpr int MAX_GROUPS = 2, MAX_DEVICES = 64;
+struct side_streams { hipStream_t s[MAX_GROUPS - 1]; hipEvent_t fork, join[MAX_GROUPS - 1]; int n; };
 
-inline side_streams* side_streams_of_device()
+// the library's side streams of the current device, at least `want` of them (created on first use, kept until the process ends;
+// default priority, non-blocking: a process has few hardware queues - GPU_MAX_HW_QUEUES - and every stream ever created keeps
+// a share of one, so no more are made than a call uses)
+inline side_streams* side_streams_of_device(int want)
 {
     static side_streams table[MAX_DEVICES] = {};
     static std::mutex mu;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    if (want > MAX_GROUPS - 1 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
     side_streams& e = table[dev];
-    if (!e.ok) {
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-        for (int i = 0; i < MAX_GROUPS - 1; ++i) {
-            if (hipStreamCreateWithPriority(&e.s[i], hipStreamNonBlocking, hi) != hipSuccess) return nullptr;
-            if (hipEventCreateWithFlags(&e.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        }
-        e.ok = true;
+    if (!e.fork && hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    while (e.n < want) {
+        if (hipStreamCreateWithFlags(&e.s[e.n], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&e.join[e.n], hipEventDisableTiming) != hipSuccess) return nullptr;
+        ++e.n;
     }
     return &e;
 }
@@ -59,7 +58,7 @@ inline int row_groups(int B, int tile_rows)
 template <class F>
 int run_row_groups(int ng, int L, hipStream_t stream, F launch)
 {
-    side_streams* ss = ng > 1 ? side_streams_of_device() : nullptr;
+    side_streams* ss = ng > 1 ? side_streams_of_device(ng - 1) : nullptr;
     if (ng > 1 && !ss) return GMT_ERR_HIP;
     if (ng > 1) {
         if (hipEventRecord(ss->fork, stream) != hipSuccess) return GMT_ERR_HIP;

@@ -362,13 +362,16 @@ int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const void* dh_out,
                             int ndir, float drop_p, unsigned int drop_seed, hipStream_t stream);
 
 /* Row groups (no counterpart in the reference: a scheduling knob of this library).  The rows of a batch are independent
- * recurrences, so gmt_bf16_lstm_layer_fwd / _bwd and gmt_bf16_gen_rollout_fwd / _bwd run a call as n independent chains of step
- * launches over B / n rows each - chain 0 on the caller's stream, the others on streams the library owns (one set per device,
- * created on first use), forked from and joined to the caller's stream by events, so the call stays in order for the caller.
- * The workgroups of one launch move in lock-step (contraction, then the HBM-heavy epilogue); two chains overlap one's
- * epilogue and launch boundary with the other's MFMAs.  Results do not depend on n.  n in 1..4 (default 2, or the
- * environment's GMT_BF16_ROW_GROUPS); a call falls back to fewer groups when B / n is not a multiple of four row tiles.
- * With n > 1 these calls must not be made under HIP stream capture of a single stream without cross-stream capture. */
+ * recurrences, so gmt_bf16_lstm_layer_fwd / _bwd and gmt_bf16_gen_rollout_fwd / _bwd can run a call as two independent chains of
+ * step launches over B / 2 rows each - chain 0 on the caller's stream, chain 1 on a stream the library owns (one per device,
+ * created on first use, default priority, non-blocking), forked from and joined to the caller's stream by events, so the call
+ * stays in order for the caller.  The workgroups of one launch move in lock-step (contraction, then the HBM-heavy epilogue);
+ * two chains overlap one's epilogue and launch boundary with the other's MFMAs.  Results do not depend on n (bit-identical).
+ * n = 1 or 2 (default 2, or the environment's GMT_BF16_ROW_GROUPS); a call uses one chain when B / 2 is not a multiple of four
+ * row tiles.  The library deliberately owns ONE extra stream per device: a process has GPU_MAX_HW_QUEUES (4) hardware queues
+ * per priority, and with three library streams alive a later two-stream sequence of the fp32 path
+ * (Trainer.overlap_g_forward's high-priority torch stream) never completed on this stack.
+ * With n = 2 these calls must not be made under single-stream HIP graph capture. */
 int gmt_bf16_set_row_groups(int n);
 
 /* Gradient penalty at this width (compute_gradient_penalty, RG.py:790-842; full-length batches only).

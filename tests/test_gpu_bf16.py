@@ -475,10 +475,10 @@ def test_bf16_train_steps_vs_fp64_oracle():
 
 
 def test_bf16_row_groups_do_not_change_results():
-    """gmt_bf16_set_row_groups (include/gmt_hip.h): the critic's layer sweeps and the generator's rollout / BPTT run as 1, 2 or
-    4 independent chains of step launches over disjoint row ranges on the library's own streams.  Same arithmetic per row, so
-    scores, outputs and every gradient must be BIT-identical to the single-chain run (1 024 ragged rows, H = 512, with both
-    dropout masks on; 4 groups fall back to 2 where 256 rows are not four tiles)."""
+    """gmt_bf16_set_row_groups (include/gmt_hip.h): the critic's layer sweeps and the generator's rollout / BPTT run as one or
+    two independent chains of step launches over disjoint row ranges (the second on the library's own stream).  Same
+    arithmetic per row, so scores, outputs and every gradient must be BIT-identical to the single-chain run (1 024 ragged
+    rows, H = 512, with both dropout masks on)."""
     import generative_mouse_trajectories_amd as gmt
     L_ = _L()
     over = dict(latent_dim=16, generator_hidden_dim=512, discriminator_hidden_dim=512)
@@ -519,7 +519,7 @@ def test_bf16_row_groups_do_not_change_results():
     try:
         L_.call('gmt_bf16_set_row_groups', 1)
         one = run()
-        for n in (2, 4):
+        for n in (2,):
             L_.call('gmt_bf16_set_row_groups', n)
             many = run()
             assert many.keys() == one.keys()
