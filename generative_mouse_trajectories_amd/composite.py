@@ -58,13 +58,12 @@ def discriminator_forward_gp(D, trajectories: torch.Tensor, dts: torch.Tensor, l
     if getattr(D, 'bf16', False):
         # H = 512 (BASELINE configs[2]): the whole BiLSTM stack is ONE twice-differentiable op on the bf16 step kernels
         from . import ops_bf16
-        if int(lens.min().item()) < pos.shape[0]:
-            raise NotImplementedError('compute_dtype bf16: the gradient penalty is built for full-length batches')
         Bq = (B + ops_bf16.ROW_TILE - 1) // ops_bf16.ROW_TILE * ops_bf16.ROW_TILE
         if Bq != Bp:
             x = _pad_batch(x[:, :B], Bq, 1)
+            lens = _pad_batch(lens[:B], Bq, 0, 1)
         lw = [w for l in range(nl) for w in D.lstm.layer_weights(l)]
-        h_final = ops_bf16.lstm_stack_gp(x.contiguous(), nl, lw)
+        h_final = ops_bf16.lstm_stack_gp(x.contiguous(), nl, lw, lens)
         return D.run_sequential(D.output_layers, h_final[:B], sn_w)
     h_final = None
     for l in range(nl):

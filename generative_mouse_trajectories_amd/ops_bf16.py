@@ -13,7 +13,7 @@ Function so that the big buffers are reused in place (gates -> d(pre-activation)
 The generator (RG.py:551-719) is the same idea with three launches per step (`gmt_bf16_gen_rollout_fwd/bwd`,
 `GenRolloutBf16Fn`), and the gradient penalty's double backward through the BiLSTM stack is `LSTMStackGPFn` /
 `LSTMStackBwdGPFn` over `gmt_bf16_lstm_layer_bwd_gp/_bwd2`.  Limits (refused loudly): generator
-H = 512 only, no in-kernel early stop, penalty on full-length batches with a dropout-free critic."""
+H = 512 only, no in-kernel early stop, the penalty's critic pass without the inter-layer dropout mask."""
 from __future__ import annotations
 
 from typing import List, Optional
@@ -428,16 +428,33 @@ class _Saved:
     """What the stack's forward keeps for its two backward forms (a plain Python holder: not a tensor argument)."""
     def __init__(self):
         self.layers, self.dims, self.first = [], None, None
+        self.valid, self.last = None, None      # ragged batches: [M] 0/1 per row-step (bf16), row index of (len-1, b) per trajectory
+
+
+def _mask_g_(X: torch.Tensor, valid: Optional[torch.Tensor], H: int, nd: int = 2) -> torch.Tensor:
+    """Ragged batches on the full-length step kernels.  X [M, nd*4H] lives in pre-activation space (slab column order).  The
+    backward direction of a packed sequence (RG.py:764-772) starts at t = len-1 from zero state; the full-length kernels start
+    at t = L-1.  Zeroing the HOISTED part of gate g's pre-activation at the row-steps t >= len of direction 1 keeps that
+    direction's state exactly zero there (h = 0 -> the recurrent part of a_g is 0 -> g = 0 -> c = i g = 0 -> h = 0, by
+    induction from the zero initial state), whatever the parameters and inputs: the masked full-length layer IS the packed
+    layer as a function, so its derivatives of every order are too.  The mask is the linear map pre -> M * pre between the
+    GEMMs and the sweeps, so it is applied wherever a quantity crosses that boundary (pre, d pre, the adjoint sweep's hoisted
+    term).  Direction 0 needs no mask: steps t >= len come after everything that is read (final state = h at t = len-1)."""
+    if valid is not None:
+        v = X.view(X.shape[0], nd, H // 32, 4, 32)
+        v[:, 1, :, 2, :] *= valid.to(X.dtype)[:, None, None]
+    return X
 
 
 class LSTMStackGPFn(torch.autograd.Function):
-    """e [L, B, H] fp32 (the feature encoder's output; full-length rows only), the LSTM parameters -> h_final [B, 2H] fp32.
+    """e [L, B, H] fp32 (the feature encoder's output), lengths [B] or None, the LSTM parameters -> h_final [B, 2H] fp32.
+    Ragged batches run on the same full-length kernels behind a mask (_mask_g_).
     Under create_graph=True (the penalty's autograd.grad w.r.t. the interpolated positions) its backward is the differentiable
     op LSTMStackBwdGPFn; the penalty's own backward then runs the second-order sweep.  Inter-layer dropout is NOT applied on
     this pass (the reference draws a fresh mask here too; statistically the penalty is that of the dropout-free critic)."""
 
     @staticmethod
-    def forward(ctx, e, n_layers, *lw):
+    def forward(ctx, e, lengths, n_layers, *lw):
         L, B, H = e.shape
         nd = 2
         if B % ROW_TILE or H % 256:
@@ -446,11 +463,15 @@ class LSTMStackGPFn(torch.autograd.Function):
         M = L * B
         hold = _Saved()
         hold.dims = (L, B, H, nd, int(n_layers))
+        if lengths is not None and int(lengths.min().item()) < L:
+            ln = lengths.to(device=dev, dtype=torch.int64).clamp(1, L)
+            hold.valid = (torch.arange(L, device=dev)[:, None] < ln[None, :]).reshape(M).to(BF16)
+            hold.last = (ln - 1) * B + torch.arange(B, device=dev)
         x = e.detach().reshape(M, H).to(BF16).contiguous()
         for l in range(n_layers):
             ws = list(lw[4 * nd * l: 4 * nd * (l + 1)])
             wih, bias, whh, whhT, wihT = lstm_layer_weights(ws, H, nd)
-            G = gemm_nt(x, wih, bias, None, 0, 0.0, label=f'bf16_gp_pre_l{l}')
+            G = _mask_g_(gemm_nt(x, wih, bias, None, 0, 0.0, label=f'bf16_gp_pre_l{l}'), hold.valid, H, nd)
             c_all = torch.empty(M, nd * H, device=dev, dtype=torch.float32)
             h_all = torch.empty(M, nd * H, device=dev, dtype=BF16)
             L_.call('gmt_bf16_lstm_layer_fwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(h_all), None, L_.ptr(whh), None, 0, L, B, H, nd,
@@ -460,7 +481,8 @@ class LSTMStackGPFn(torch.autograd.Function):
         ctx.hold = hold
         ctx.save_for_backward(e, *lw)
         ctx.set_materialize_grads(False)
-        return torch.cat([x[(L - 1) * B:, :H], x[:B, H:]], 1).float()
+        h_fwd = x[(L - 1) * B:, :H] if hold.last is None else x[hold.last, :H]      # direction 0: h at t = len-1
+        return torch.cat([h_fwd, x[:B, H:]], 1).float()
 
     @staticmethod
     def backward(ctx, dh_final):
@@ -469,14 +491,14 @@ class LSTMStackGPFn(torch.autograd.Function):
             # first backward under create_graph=True (the penalty's autograd.grad w.r.t. the interpolated positions): only the
             # input gradient is asked for, and it is produced by a differentiable op
             de = LSTMStackBwdGPFn.apply(dh_final, e, ctx.hold, *lw)
-            return (de, None) + (None,) * len(lw)
+            return (de, None, None) + (None,) * len(lw)
         # The penalty's own backward reaches this node once more, through the head's double backward (the adjoint of h_final
         # as a saved activation of the head).  The head is piecewise linear, so that adjoint is identically zero: nothing to add
         # to what LSTMStackBwdGPFn.backward already returned.  Anything else is not the gradient penalty.
         hold = ctx.hold
         hold.layers, hold.first = [], None
         if dh_final is None or not bool(dh_final.any().item()):
-            return (None, None) + (None,) * len(lw)
+            return (None, None, None) + (None,) * len(lw)
         raise L_.GmtError('LSTMStackGPFn serves the gradient penalty only; the ordinary critic pass is ops_bf16.critic_body')
 
 
@@ -495,6 +517,11 @@ class LSTMStackBwdGPFn(torch.autograd.Function):
         dcc = torch.empty(nd, B, H, device=dev, dtype=torch.float32)
         first = []
         dh_out = None
+        if hold.last is not None:
+            # ragged: direction 0's final state was read at t = len-1, so its gradient enters there, as a gradient of h_all
+            dh_out = torch.zeros(M, nd * H, device=dev, dtype=BF16)
+            dh_out[hold.last, :H] = dh_final[:, :H].to(BF16)
+            dh_fin[0].zero_()
         for l in range(n_layers - 1, -1, -1):
             x, G, c_all, h_all = hold.layers[l]
             ws = list(lw[4 * nd * l: 4 * nd * (l + 1)])
@@ -505,8 +532,11 @@ class LSTMStackBwdGPFn(torch.autograd.Function):
             L_.call('gmt_bf16_lstm_layer_bwd_gp', L_.ptr(G), L_.ptr(da), L_.ptr(c_all), L_.ptr(dh_out), L_.ptr(dh_fin), None, None,
                     L_.ptr(dct), L_.ptr(dht), L_.ptr(dcc), L_.ptr(whhT), L, B, H, nd, L_.stream(), label='bf16_gp_lstm_bwd',
                     flops=2.0 * (L - 1) * B * nd * 4 * H * H)
-            first.insert(0, (da, dct, dht))
-            dh_out = gemm_nt(da, wihT, None, None, 0, 0.0, label=f'bf16_gp_dx_l{l}')
+            # da is the gradient of the TOTAL pre-activation (what the sweep contracts with W_hh); what the GEMM side sees
+            # (dX, and later the W_ih terms) is M * da
+            da_m = da if hold.valid is None else _mask_g_(da.clone(), hold.valid, H, nd)
+            first.insert(0, (da, dct, dht, da_m))
+            dh_out = gemm_nt(da_m, wihT, None, None, 0, 0.0, label=f'bf16_gp_dx_l{l}')
             dh_fin = torch.zeros_like(dh_fin)
         hold.first = first
         ctx.hold = hold
@@ -528,10 +558,10 @@ class LSTMStackBwdGPFn(torch.autograd.Function):
         hhat_fin = None
         for l in range(n_layers):                      # the adjoint chain runs bottom-up: layer 0's sweep produced de
             x, G, c_all, h_all = hold.layers[l]
-            da, dct, dht = hold.first[l]
+            da, dct, dht, da_m = hold.first[l]
             ws = list(lw[4 * nd * l: 4 * nd * (l + 1)])
             wih, bias, whh, whhT, wihT = lstm_layer_weights(ws, H, nd)
-            PH = gemm_nt(xh, wih, None, None, 0, 0.0, label=f'bf16_gp_prehat_l{l}')
+            PH = _mask_g_(gemm_nt(xh, wih, None, None, 0, 0.0, label=f'bf16_gp_prehat_l{l}'), hold.valid, H, nd)
             hhat = torch.empty(M, nd * H, device=dev, dtype=BF16)
             hhat_fin = torch.empty(nd, B, H, device=dev, dtype=torch.float32)
             gg = torch.empty(M, nd * 4 * H, device=dev, dtype=torch.float32)
@@ -541,7 +571,7 @@ class LSTMStackBwdGPFn(torch.autograd.Function):
                     L_.ptr(hhat_fin), L_.ptr(gg), L_.ptr(gc), L_.ptr(chat), L_.ptr(whh), L, B, H, nd, L_.stream(),
                     label='bf16_gp_lstm_bwd2', flops=2.0 * (L - 1) * B * nd * 4 * H * H)
             # explicit weight terms of the first backward sweep: dX = da W_ih, dh_t = dh_out[t] + da_{t+-1} W_hh
-            e_wih = wgrad_tn(da, xh, label='bf16_gp_wgrad_ih2')
+            e_wih = wgrad_tn(da_m, xh, label='bf16_gp_wgrad_ih2')
             for d in range(nd):
                 cols = slice(d * 4 * H, (d + 1) * 4 * H)
                 if d == 0:
@@ -553,7 +583,9 @@ class LSTMStackBwdGPFn(torch.autograd.Function):
                 g_lw[k + 1] = slab_unperm_rows(e_whh, H)
             second.append((gg, gc))
             xh = hhat
-        hhat_final = torch.cat([hhat_fin[0], hhat_fin[1]], 1)
+        # adjoint of dh_final: direction 0's entered the sweep through dh_out at t = len-1 when the batch is ragged
+        hhat_fwd = hhat_fin[0] if hold.last is None else xh[hold.last, :H].float()
+        hhat_final = torch.cat([hhat_fwd, hhat_fin[1]], 1)
         # ordinary backward sweep through the forward pass, fed by the adjoints of its saved activations
         zero_fin = torch.zeros(nd, B, H, device=dev, dtype=torch.float32)
         dcc = torch.empty(nd, B, H, device=dev, dtype=torch.float32)
@@ -568,17 +600,16 @@ class LSTMStackBwdGPFn(torch.autograd.Function):
             L_.call('gmt_bf16_lstm_layer_bwd_gp', L_.ptr(G), L_.ptr(da2), L_.ptr(c_all), L_.ptr(dh_out), L_.ptr(zero_fin), L_.ptr(gg),
                     L_.ptr(gc), None, None, L_.ptr(dcc), L_.ptr(whhT), L, B, H, nd, L_.stream(), label='bf16_gp_lstm_bwd_x',
                     flops=2.0 * (L - 1) * B * nd * 4 * H * H)
+            d_whh = [wgrad_tn(da2[B:, :4 * H], h_all[:M - B, :H], label='bf16_gp_wgrad_hh'),      # the W_hh terms: total d(pre-activation)
+                     wgrad_tn(da2[:M - B, 4 * H:], h_all[B:, H:], label='bf16_gp_wgrad_hh')]
+            _mask_g_(da2, hold.valid, H, nd)                                                   # the GEMM side: M * da2
             d_wih = wgrad_tn(da2, x, label='bf16_gp_wgrad_ih')
             db = da2.sum(0, dtype=torch.float32)
             for d in range(nd):
                 cols = slice(d * 4 * H, (d + 1) * 4 * H)
-                if d == 0:
-                    d_whh = wgrad_tn(da2[B:, cols], h_all[:M - B, :H], label='bf16_gp_wgrad_hh')
-                else:
-                    d_whh = wgrad_tn(da2[:M - B, cols], h_all[B:, H:], label='bf16_gp_wgrad_hh')
                 k = 4 * nd * l + 4 * d
                 g_lw[k] = g_lw[k] + slab_unperm_rows(d_wih[cols], H)
-                g_lw[k + 1] = g_lw[k + 1] + slab_unperm_rows(d_whh, H)
+                g_lw[k + 1] = g_lw[k + 1] + slab_unperm_rows(d_whh[d], H)
                 g_lw[k + 2] = slab_unperm_rows(db[cols], H)
                 g_lw[k + 3] = g_lw[k + 2]
             dx = gemm_nt(da2, wihT, None, None, 0, 0.0, label=f'bf16_gp_dx2_l{l}')
@@ -589,5 +620,6 @@ class LSTMStackBwdGPFn(torch.autograd.Function):
         return (hhat_final, g_e, None, *g_lw)
 
 
-def lstm_stack_gp(e, n_layers, lstm_weights):
-    return LSTMStackGPFn.apply(e, n_layers, *lstm_weights)
+def lstm_stack_gp(e, n_layers, lstm_weights, lengths=None):
+    """lengths [B] (valid steps per row, 1..L) or None for full-length rows."""
+    return LSTMStackGPFn.apply(e, lengths, n_layers, *lstm_weights)

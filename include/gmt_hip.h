@@ -374,7 +374,9 @@ int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const void* dh_out,
  * With n = 2 these calls must not be made under single-stream HIP graph capture. */
 int gmt_bf16_set_row_groups(int n);
 
-/* Gradient penalty at this width (compute_gradient_penalty, RG.py:790-842; full-length batches only).
+/* Gradient penalty at this width (compute_gradient_penalty, RG.py:790-842).  The two entry points below sweep full-length
+ * rows; the host runs ragged batches on them behind a pre-activation mask (ops_bf16._mask_g_: the hoisted part of gate g of
+ * direction 1 is zeroed at t >= len, which keeps that direction's state exactly zero there).
  * gmt_bf16_lstm_layer_bwd_gp: the backward sweep out of place (gates is kept, dA [L][B][ndir*4H] bf16 is written), which can also
  * keep the per-step totals dct_all / dht_all [L][B][ndir*H] fp32 the second-order sweep needs (first backward under
  * create_graph=True), and take the adjoints of the saved activations as extra inputs (gg_in [L][B][ndir*4H], gc_in

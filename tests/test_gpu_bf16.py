@@ -313,7 +313,7 @@ def test_bf16_generator_refuses_what_is_not_built():
     assert out.shape[0] == 4 and out.shape[2] == 3 and lengths.shape == (4,)
 
 
-def _gp_case(Hd, Bs, T, seed, dt_scale):
+def _gp_case(Hd, Bs, T, seed, dt_scale, ragged=False):
     """compute_gradient_penalty (RG.py:790-842) through the bf16 critic: value and the gradient of the penalty w.r.t. every
     critic parameter (the second-order sweep) against the fp64 oracle."""
     import generative_mouse_trajectories_amd as gmt
@@ -329,13 +329,17 @@ def _gp_case(Hd, Bs, T, seed, dt_scale):
     sd.update({k: torch.from_numpy(v) for k, v in bd.items()})
     D.load_state_dict(sd, strict=True)
     D = D.to(DEV).train()
-    br = H.batch_t(Bs, T, seed + 1, [T] * Bs, torch.float32)
-    bf = H.batch_t(Bs, T, seed + 2, [T] * Bs, torch.float32)
+    seq_len = [T] * Bs
+    if ragged:
+        seq_len = np.random.default_rng(seed + 4).integers(T // 2, T + 1, Bs).tolist()
+        seq_len[0] = T
+    br = H.batch_t(Bs, T, seed + 1, seq_len, torch.float32)
+    bf = H.batch_t(Bs, T, seed + 2, seq_len, torch.float32)
     rt = gmt.trajectory_to_absolute(br['starts'], br['sequences'][:, :, :2])
     ft = gmt.trajectory_to_absolute(bf['starts'], bf['sequences'][:, :, :2])
     rd = torch.nn.functional.pad(br['sequences'][:, :, 2], (1, 0), value=0.001) * dt_scale
     fd = torch.nn.functional.pad(bf['sequences'][:, :, 2], (1, 0), value=0.001) * dt_scale
-    lens = torch.full((Bs,), T + 1)
+    lens = torch.tensor(seq_len) + 1
     alpha = torch.rand(Bs, 1, 1, generator=torch.Generator().manual_seed(seed + 3))
     D.zero_grad()
     gp = gmt.compute_gradient_penalty(D, rt.to(DEV), ft.to(DEV), rd.to(DEV), fd.to(DEV), lens.to(DEV), DEV, alpha=alpha.to(DEV))
@@ -354,7 +358,7 @@ def _gp_case(Hd, Bs, T, seed, dt_scale):
         cosines[k] = float(a @ c / (a.norm() * c.norm()))
     e_v = abs(gp.item() - ref.item()) / abs(ref.item())
     kmax = max(err, key=lambda k: err[k])
-    print(f'bf16 gradient penalty H={Hd} B={Bs} T={T}: value {gp.item():.4f} vs {ref.item():.4f} ({e_v:.1e}); parameter gradients: '
+    print(f'bf16 gradient penalty H={Hd} B={Bs} T={T} ragged={ragged}: value {gp.item():.4f} vs {ref.item():.4f} ({e_v:.1e}); parameter gradients: '
           f'worst relative L2 error {err[kmax]:.1e} ({kmax}), lowest cosine {min(cosines.values()):.4f}')
     return e_v, err, cosines
 
@@ -369,6 +373,64 @@ def test_bf16_gradient_penalty_vs_fp64_oracle():
     assert e_v <= 1.5e-1
     for k in err:
         assert err[k] <= 1.5e-1 and cosines[k] >= 0.99, (k, err[k], cosines[k])
+
+
+def test_bf16_gradient_penalty_ragged_vs_fp64_oracle():
+    """The same with ragged lengths (T/2 .. T steps per row; RG.py:764-772 packs the sequences): the full-length step kernels
+    behind the pre-activation mask of ops_bf16._mask_g_, direction 0's final state gathered at t = len-1.  Measured: value
+    2.6e-2, worst relative L2 error 1.4e-1, lowest cosine 0.990 (the bf16 noise of this comparison varies with the data: 0.1-0.25
+    over seeds for ragged and full-length batches alike, scratch/dbg_gp_ragged.py); bars 1.5e-1 / 2e-1 / 0.985.  That the
+    mask construction itself is exact is the next test."""
+    e_v, err, cosines = _gp_case(256, 64, 16, 151, 50.0, ragged=True)
+    assert e_v <= 1.5e-1
+    for k in err:
+        assert err[k] <= 2e-1 and cosines[k] >= 0.985, (k, err[k], cosines[k])
+
+
+def test_bf16_gradient_penalty_ragged_mask_is_exact():
+    """A batch whose rows all have length 10 inside T = 16 (the ragged path: mask, gather, injected final-state gradient)
+    against the same data truncated to T = 10 (the full-length path).  The arithmetic at the valid steps is the same, so
+    the penalty and every parameter gradient must agree far below the bf16-vs-fp64 distance: measured 5-9e-3 (the final-state
+    gradient enters the ragged sweep rounded to bf16), bar 2e-2."""
+    import generative_mouse_trajectories_amd as gmt
+    over = dict(latent_dim=8, generator_hidden_dim=32, discriminator_hidden_dim=256)
+    cfg = gmt.Config()
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    cfg.lstm_dropout = cfg.head_dropout = 0.0
+    cfg.compute_dtype = 'bf16'
+    pd, bd = PG.make_discriminator_params(O.OracleConfig(**over), 131)
+    Bs, T, Tv = 64, 16, 10
+    br = H.batch_t(Bs, T, 132, [Tv] * Bs, torch.float32)
+    bf = H.batch_t(Bs, T, 133, [Tv] * Bs, torch.float32)
+    alpha = torch.rand(Bs, 1, 1, generator=torch.Generator().manual_seed(134))
+
+    def run(Tc):
+        D = gmt.Discriminator(cfg)
+        sd = {k: torch.from_numpy(v) for k, v in pd.items()}
+        sd.update({k: torch.from_numpy(v) for k, v in bd.items()})
+        D.load_state_dict(sd, strict=True)
+        D = D.to(DEV).train()
+        rt = gmt.trajectory_to_absolute(br['starts'], br['sequences'][:, :Tc, :2])
+        ft = gmt.trajectory_to_absolute(bf['starts'], bf['sequences'][:, :Tc, :2])
+        rd = torch.nn.functional.pad(br['sequences'][:, :Tc, 2], (1, 0), value=0.001) * 50.0
+        fd = torch.nn.functional.pad(bf['sequences'][:, :Tc, 2], (1, 0), value=0.001) * 50.0
+        lens = torch.full((Bs,), Tv + 1)
+        gp = gmt.compute_gradient_penalty(D, rt.to(DEV), ft.to(DEV), rd.to(DEV), fd.to(DEV), lens.to(DEV), DEV, alpha=alpha.to(DEV))
+        gp.backward()
+        return gp.item(), {k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None}
+
+    v_full, g_full = run(Tv)
+    v_rag, g_rag = run(T)
+    assert abs(v_rag - v_full) <= 2e-2 * abs(v_full), (v_rag, v_full)
+    worst = 0.0
+    for k, a in g_full.items():
+        if float(a.norm()) == 0.0:
+            continue
+        e = float((g_rag[k].double() - a.double()).norm() / a.double().norm())
+        worst = max(worst, e)
+        assert e <= 2e-2, (k, e)
+    print(f'bf16 gradient penalty, masked ragged path vs truncated full-length path: penalty {v_rag:.4f} vs {v_full:.4f}, worst gradient {worst:.1e}')
 
 
 def test_bf16_gradient_penalty_step_kernels():
@@ -425,7 +487,8 @@ def test_bf16_gradient_penalty_step_kernels():
     H.assert_close(planes(gc), gc32, 1e-2, 'adjoint of the saved cell states')
 
 
-def test_bf16_train_steps_vs_fp64_oracle():
+@pytest.mark.parametrize('ragged', [False, True])
+def test_bf16_train_steps_vs_fp64_oracle(ragged):
     """One full D step (with the gradient penalty on a quarter of the batch) and one G step of the Trainer with BOTH networks
     at H = 512 on the bf16 kernels (BASELINE configs[2]'s width; T = 16, 256 full-length trajectories, time steps x 50 so the
     features are O(1), dropout off for a deterministic comparison): every returned metric against the oracle's step functions
@@ -450,7 +513,8 @@ def test_bf16_train_steps_vs_fp64_oracle():
     tr = gmt.Trainer(G.to(DEV).train(), D.to(DEV).train(), cfg, torch.device(DEV), '/tmp/runs_gpu_bf16')
     tr.epoch = 30
     Bs, T = 256, 16
-    b = H.batch_t(Bs, T, 143, [T] * Bs, torch.float32)
+    lengths = np.random.default_rng(146).integers(T // 2, T + 1, Bs).tolist() if ragged else [T] * Bs   # ragged: also through the penalty
+    b = H.batch_t(Bs, T, 143, lengths, torch.float32)
     b['sequences'][:, :, 2] *= 50.0
     g = torch.Generator().manual_seed(144)
     nb = -(-Bs // 4)
@@ -466,6 +530,7 @@ def test_bf16_train_steps_vs_fp64_oracle():
     bb = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in b.items()}
     md, _, _ = O.discriminator_step(Pg, Pd, Bd, {}, bb, {'z': noise['z'].to(dt), 'gp_idx': noise['gp_idx'], 'alpha': noise['alpha'].to(dt)}, oc, 0)
     mg, _, _ = O.generator_step(Pg, Pd, Bd, {}, bb, {'z': zg.to(dt)}, oc, mask_tf, tr.get_teacher_forcing_ratio())
+    print(f'ragged={ragged}')
     print('bf16 D step:', {k: (round(m_d[k], 5), round(float(v), 5)) for k, v in md.items()})
     print('bf16 G step:', {k: (round(m_g[k], 5), round(float(v), 5)) for k, v in mg.items()})
     for got, ref in ((m_d, md), (m_g, mg)):
