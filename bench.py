@@ -254,7 +254,7 @@ def bench_config3(args, dev):
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
            'dtype': 'bf16 operands / f32 accumulate, state, parameter gradients and optimizer', 'data': 'synthetic',
            'config': {'workload': f'BASELINE configs[2]: WGAN-GP train step (D step + G step), B={B}, T={T}, H_g=H_d={Hd}, latent {LATENT}, '
-                                  'n_critic 1, GP every 4th D step on 25% of the batch (dropout-free critic inside the penalty), '
+                                  'n_critic 1, GP every 4th D step on 25% of the batch, '
                                   'teacher-forcing ratio 0', 'global_batch': B, 'seq_len': T, 'parallelism': 'dp1',
                       'lstm_dropout': cfg.lstm_dropout, 'head_dropout': cfg.head_dropout},
            'model_flops_per_trajectory': fl, 'step_tflops': fl * B / dt / 1e12,

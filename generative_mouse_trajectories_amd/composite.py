@@ -63,7 +63,8 @@ def discriminator_forward_gp(D, trajectories: torch.Tensor, dts: torch.Tensor, l
             x = _pad_batch(x[:, :B], Bq, 1)
             lens = _pad_batch(lens[:B], Bq, 0, 1)
         lw = [w for l in range(nl) for w in D.lstm.layer_weights(l)]
-        h_final = ops_bf16.lstm_stack_gp(x.contiguous(), nl, lw, lens)
+        drop_p = cfg.lstm_dropout if (D.training and nl > 1) else 0.0
+        h_final = ops_bf16.lstm_stack_gp(x.contiguous(), nl, lw, lens, drop_p)
         return D.run_sequential(D.output_layers, h_final[:B], sn_w)
     h_final = None
     for l in range(nl):

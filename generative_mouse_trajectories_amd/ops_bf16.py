@@ -13,7 +13,7 @@ Function so that the big buffers are reused in place (gates -> d(pre-activation)
 The generator (RG.py:551-719) is the same idea with three launches per step (`gmt_bf16_gen_rollout_fwd/bwd`,
 `GenRolloutBf16Fn`), and the gradient penalty's double backward through the BiLSTM stack is `LSTMStackGPFn` /
 `LSTMStackBwdGPFn` over `gmt_bf16_lstm_layer_bwd_gp/_bwd2`.  Limits (refused loudly): generator
-H = 512 only, no in-kernel early stop, the penalty's critic pass without the inter-layer dropout mask."""
+H = 512 only, no in-kernel early stop."""
 from __future__ import annotations
 
 from typing import List, Optional
@@ -429,6 +429,17 @@ class _Saved:
     def __init__(self):
         self.layers, self.dims, self.first = [], None, None
         self.valid, self.last = None, None      # ragged batches: [M] 0/1 per row-step (bf16), row index of (len-1, b) per trajectory
+        self.drop = []                          # inter-layer dropout masks [M, nd*H] fp32 (0 or 1/(1-p)), one per layer boundary
+
+
+def gp_drop_mask(L: int, B: int, width: int, p: float, device) -> torch.Tensor:
+    """nn.LSTM's inter-layer dropout mask for the penalty's critic pass (RG.py:725 under D.train(), RG.py:822): a fresh draw, as
+    in the reference; [L*B, width] fp32 of 0 / 1/(1-p).  (The tests replace this function to replay a known mask.)"""
+    return (torch.rand(L * B, width, device=device) >= p).float() / (1.0 - p)
+
+
+def _drop(x: torch.Tensor, mk: Optional[torch.Tensor]) -> torch.Tensor:
+    return x if mk is None else (x.float() * mk).to(x.dtype)
 
 
 def _mask_g_(X: torch.Tensor, valid: Optional[torch.Tensor], H: int, nd: int = 2) -> torch.Tensor:
@@ -450,11 +461,11 @@ class LSTMStackGPFn(torch.autograd.Function):
     """e [L, B, H] fp32 (the feature encoder's output), lengths [B] or None, the LSTM parameters -> h_final [B, 2H] fp32.
     Ragged batches run on the same full-length kernels behind a mask (_mask_g_).
     Under create_graph=True (the penalty's autograd.grad w.r.t. the interpolated positions) its backward is the differentiable
-    op LSTMStackBwdGPFn; the penalty's own backward then runs the second-order sweep.  Inter-layer dropout is NOT applied on
-    this pass (the reference draws a fresh mask here too; statistically the penalty is that of the dropout-free critic)."""
+    op LSTMStackBwdGPFn; the penalty's own backward then runs the second-order sweep.  Inter-layer dropout (drop_p > 0) is a
+    fresh mask per call (gp_drop_mask), a linear map between the layers that every pass applies at the same place."""
 
     @staticmethod
-    def forward(ctx, e, lengths, n_layers, *lw):
+    def forward(ctx, e, lengths, drop_p, n_layers, *lw):
         L, B, H = e.shape
         nd = 2
         if B % ROW_TILE or H % 256:
@@ -477,10 +488,13 @@ class LSTMStackGPFn(torch.autograd.Function):
             L_.call('gmt_bf16_lstm_layer_fwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(h_all), None, L_.ptr(whh), None, 0, L, B, H, nd,
                     0.0, 0, L_.stream(), label='bf16_gp_lstm_fwd', flops=2.0 * (L - 1) * B * nd * 4 * H * H)
             hold.layers.append((x, G, c_all, h_all))
-            x = h_all
+            mk = gp_drop_mask(L, B, nd * H, float(drop_p), dev) if (drop_p and l + 1 < n_layers) else None
+            hold.drop.append(mk)
+            x = _drop(h_all, mk)                # the next layer reads h through the mask; the recurrence and the output do not
         ctx.hold = hold
         ctx.save_for_backward(e, *lw)
         ctx.set_materialize_grads(False)
+        x = hold.layers[-1][3]
         h_fwd = x[(L - 1) * B:, :H] if hold.last is None else x[hold.last, :H]      # direction 0: h at t = len-1
         return torch.cat([h_fwd, x[:B, H:]], 1).float()
 
@@ -491,14 +505,14 @@ class LSTMStackGPFn(torch.autograd.Function):
             # first backward under create_graph=True (the penalty's autograd.grad w.r.t. the interpolated positions): only the
             # input gradient is asked for, and it is produced by a differentiable op
             de = LSTMStackBwdGPFn.apply(dh_final, e, ctx.hold, *lw)
-            return (de, None, None) + (None,) * len(lw)
+            return (de, None, None, None) + (None,) * len(lw)
         # The penalty's own backward reaches this node once more, through the head's double backward (the adjoint of h_final
         # as a saved activation of the head).  The head is piecewise linear, so that adjoint is identically zero: nothing to add
         # to what LSTMStackBwdGPFn.backward already returned.  Anything else is not the gradient penalty.
         hold = ctx.hold
         hold.layers, hold.first = [], None
         if dh_final is None or not bool(dh_final.any().item()):
-            return (None, None, None) + (None,) * len(lw)
+            return (None, None, None, None) + (None,) * len(lw)
         raise L_.GmtError('LSTMStackGPFn serves the gradient penalty only; the ordinary critic pass is ops_bf16.critic_body')
 
 
@@ -537,6 +551,8 @@ class LSTMStackBwdGPFn(torch.autograd.Function):
             da_m = da if hold.valid is None else _mask_g_(da.clone(), hold.valid, H, nd)
             first.insert(0, (da, dct, dht, da_m))
             dh_out = gemm_nt(da_m, wihT, None, None, 0, 0.0, label=f'bf16_gp_dx_l{l}')
+            if l > 0:
+                dh_out = _drop(dh_out, hold.drop[l - 1])     # gradient of layer l-1's h_all: through the inter-layer mask
             dh_fin = torch.zeros_like(dh_fin)
         hold.first = first
         ctx.hold = hold
@@ -582,7 +598,9 @@ class LSTMStackBwdGPFn(torch.autograd.Function):
                 g_lw[k] = slab_unperm_rows(e_wih[cols], H)
                 g_lw[k + 1] = slab_unperm_rows(e_whh, H)
             second.append((gg, gc))
-            xh = hhat
+            top_hhat = hhat
+            xh = _drop(hhat, hold.drop[l])                   # the adjoint of the next layer's dX: the same linear map
+        xh = top_hhat
         # adjoint of dh_final: direction 0's entered the sweep through dh_out at t = len-1 when the batch is ragged
         hhat_fwd = hhat_fin[0] if hold.last is None else xh[hold.last, :H].float()
         hhat_final = torch.cat([hhat_fwd, hhat_fin[1]], 1)
@@ -614,12 +632,12 @@ class LSTMStackBwdGPFn(torch.autograd.Function):
                 g_lw[k + 3] = g_lw[k + 2]
             dx = gemm_nt(da2, wihT, None, None, 0, 0.0, label=f'bf16_gp_dx2_l{l}')
             if l > 0:
-                dh_out = dx
+                dh_out = _drop(dx, hold.drop[l - 1])
             else:
                 g_e = dx.float().view(L, B, H)
         return (hhat_final, g_e, None, *g_lw)
 
 
-def lstm_stack_gp(e, n_layers, lstm_weights, lengths=None):
-    """lengths [B] (valid steps per row, 1..L) or None for full-length rows."""
-    return LSTMStackGPFn.apply(e, lengths, n_layers, *lstm_weights)
+def lstm_stack_gp(e, n_layers, lstm_weights, lengths=None, drop_p=0.0):
+    """lengths [B] (valid steps per row, 1..L) or None for full-length rows; drop_p: nn.LSTM's inter-layer dropout."""
+    return LSTMStackGPFn.apply(e, lengths, float(drop_p), n_layers, *lstm_weights)

@@ -313,7 +313,7 @@ def test_bf16_generator_refuses_what_is_not_built():
     assert out.shape[0] == 4 and out.shape[2] == 3 and lengths.shape == (4,)
 
 
-def _gp_case(Hd, Bs, T, seed, dt_scale, ragged=False):
+def _gp_case(Hd, Bs, T, seed, dt_scale, ragged=False, p_drop=0.0):
     """compute_gradient_penalty (RG.py:790-842) through the bf16 critic: value and the gradient of the penalty w.r.t. every
     critic parameter (the second-order sweep) against the fp64 oracle."""
     import generative_mouse_trajectories_amd as gmt
@@ -342,11 +342,23 @@ def _gp_case(Hd, Bs, T, seed, dt_scale, ragged=False):
     lens = torch.tensor(seq_len) + 1
     alpha = torch.rand(Bs, 1, 1, generator=torch.Generator().manual_seed(seed + 3))
     D.zero_grad()
-    gp = gmt.compute_gradient_penalty(D, rt.to(DEV), ft.to(DEV), rd.to(DEV), fd.to(DEV), lens.to(DEV), DEV, alpha=alpha.to(DEV))
-    gp.backward()
+    dkw = {}
+    from generative_mouse_trajectories_amd import ops_bf16 as OB
+    fresh_mask = OB.gp_drop_mask
+    if p_drop > 0:          # the penalty's pass draws a fresh inter-layer mask: replay a known one, and hand the oracle the same
+        D.config.lstm_dropout = p_drop
+        Bq = (Bs + 255) // 256 * 256
+        mk = (torch.rand(T + 1, Bq, 2 * Hd, generator=torch.Generator().manual_seed(seed + 5)) >= p_drop).float() / (1.0 - p_drop)
+        OB.gp_drop_mask = lambda L, B, w, p, dev: mk.reshape(L * B, w).to(dev)
+        dkw = dict(training=True, lstm_dropout_masks=[mk[:, :Bs].transpose(0, 1).double()])
+    try:
+        gp = gmt.compute_gradient_penalty(D, rt.to(DEV), ft.to(DEV), rd.to(DEV), fd.to(DEV), lens.to(DEV), DEV, alpha=alpha.to(DEV))
+        gp.backward()
+    finally:
+        OB.gp_drop_mask = fresh_mask
     Pd = {k: H.t(v, torch.float64).requires_grad_(True) for k, v in pd.items()}
     Bd = {k: H.t(v, torch.float64) for k, v in bd.items()}
-    ref = O.gradient_penalty(Pd, Bd, rt.double(), ft.double(), rd.double(), fd.double(), lens, alpha.double())
+    ref = O.gradient_penalty(Pd, Bd, rt.double(), ft.double(), rd.double(), fd.double(), lens, alpha.double(), **dkw)
     keys = list(Pd.keys())
     g64 = dict(zip(keys, torch.autograd.grad(ref, [Pd[k] for k in keys], allow_unused=True)))     # (the last bias does not reach the penalty)
     err, cosines = {}, {}
@@ -358,7 +370,7 @@ def _gp_case(Hd, Bs, T, seed, dt_scale, ragged=False):
         cosines[k] = float(a @ c / (a.norm() * c.norm()))
     e_v = abs(gp.item() - ref.item()) / abs(ref.item())
     kmax = max(err, key=lambda k: err[k])
-    print(f'bf16 gradient penalty H={Hd} B={Bs} T={T} ragged={ragged}: value {gp.item():.4f} vs {ref.item():.4f} ({e_v:.1e}); parameter gradients: '
+    print(f'bf16 gradient penalty H={Hd} B={Bs} T={T} ragged={ragged} dropout={p_drop}: value {gp.item():.4f} vs {ref.item():.4f} ({e_v:.1e}); parameter gradients: '
           f'worst relative L2 error {err[kmax]:.1e} ({kmax}), lowest cosine {min(cosines.values()):.4f}')
     return e_v, err, cosines
 
@@ -382,6 +394,15 @@ def test_bf16_gradient_penalty_ragged_vs_fp64_oracle():
     over seeds for ragged and full-length batches alike, scratch/dbg_gp_ragged.py); bars 1.5e-1 / 2e-1 / 0.985.  That the
     mask construction itself is exact is the next test."""
     e_v, err, cosines = _gp_case(256, 64, 16, 151, 50.0, ragged=True)
+    assert e_v <= 1.5e-1
+    for k in err:
+        assert err[k] <= 2e-1 and cosines[k] >= 0.985, (k, err[k], cosines[k])
+
+
+def test_bf16_gradient_penalty_with_interlayer_dropout_vs_fp64_oracle():
+    """nn.LSTM's inter-layer dropout inside the penalty's critic pass (the reference's D is in train mode there, RG.py:822):
+    ragged batch, p = 0.1, the mask replayed into the oracle.  Same bars as the ragged test."""
+    e_v, err, cosines = _gp_case(256, 64, 16, 151, 50.0, ragged=True, p_drop=0.1)
     assert e_v <= 1.5e-1
     for k in err:
         assert err[k] <= 2e-1 and cosines[k] >= 0.985, (k, err[k], cosines[k])
