@@ -1,0 +1,118 @@
+"""Parity at BASELINE.json configs[2]'s stated size (B = 4096, T = 256, H_g = H_d = 512, bf16 operands / fp32 accumulation),
+where the CPU oracle is too slow to run whole: size-independent properties of the path, through the bf16 kernels.
+  * trajectories are independent: rows of the full-batch rollout / critic pass are BIT-identical to the same rows run as a
+    512-row batch (different tile grids, XCD patches, row groups - same arithmetic per row);
+  * the first rows of the full-batch results agree with the fp64 oracle at T = 256 / L = 257 to the bf16 bars of
+    tests/test_gpu_bf16.py (the errors of 256 fed-back steps are printed);
+  * gradients are additive over the batch: the critic's parameter gradients of a sum over 4096 rows equal the sum of the
+    gradients of its two halves (backward sweeps, dX and weight-gradient GEMMs over 1 M row-steps; only the fp32 summation
+    order of the weight-gradient slabs differs).
+Time steps are x 50 so that the kinematic features are O(1) (see test_gpu_bf16.py on the raw scale)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import paramgen as PG
+from oracle import gan_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+B, T, HID = 4096, 256, 512
+OVER = dict(latent_dim=64, generator_hidden_dim=HID, discriminator_hidden_dim=HID)
+
+
+def _models(seed_g, seed_d):
+    import generative_mouse_trajectories_amd as gmt
+    cfg = gmt.Config()
+    for k, v in OVER.items():
+        setattr(cfg, k, v)
+    cfg.compute_dtype = 'bf16'
+    cfg.lstm_dropout = cfg.head_dropout = 0.0      # the masks are functions of the batch shape; their parity is test_gpu_bf16.py's
+    oc = O.OracleConfig(**OVER)
+    pg = PG.make_generator_params(oc, seed_g)
+    pd, bd = PG.make_discriminator_params(oc, seed_d)
+    G, D = gmt.Generator(cfg), gmt.Discriminator(cfg)
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in pg.items()}, strict=True)
+    sd = {k: torch.from_numpy(v) for k, v in pd.items()}
+    sd.update({k: torch.from_numpy(v) for k, v in bd.items()})
+    D.load_state_dict(sd, strict=True)
+    # the critic runs in TRAINING mode: the generated spectral-norm vectors are random, and only the power iteration of a
+    # training-mode forward (RG.py:730-737) brings the weights to their normalised scale (in eval mode the untrained scores are
+    # O(1e3) and the body saturated).  Every pass starts from the same state (_critic_pass reloads it).
+    return gmt, G.to(DEV).eval(), D.to(DEV).train(), pg, pd, bd
+
+
+def _critic_pass(D, state, *args):
+    D.load_state_dict(state)
+    return D(*args)
+
+
+def _batch(seed):
+    g = torch.Generator().manual_seed(seed)
+    starts = torch.rand(B, 2, generator=g)
+    deltas = torch.randn(B, T, 2, generator=g) * 0.01
+    dts = (torch.rand(B, T, generator=g) * 0.02 + 0.004) * 50.0
+    lengths = torch.randint(T // 2, T + 1, (B,), generator=g)
+    lengths[:8] = T
+    z = torch.randn(B, OVER['latent_dim'], generator=g)
+    return starts, starts + deltas.sum(1), torch.cat([deltas, dts.unsqueeze(-1)], -1), lengths, z
+
+
+def test_bf16_rows_are_independent_and_match_the_oracle_at_config3_size():
+    gmt, G, D, pg, pd, bd = _models(5, 6)
+    starts, ends, seq, lengths, z = _batch(1)
+    sel = torch.cat([torch.arange(0, 256), torch.arange(B - 256, B)])
+    sd = sel.to(DEV)
+    with torch.no_grad():
+        full, _ = G(starts.to(DEV), ends.to(DEV), z.to(DEV), target_sequences=seq.to(DEV), tf_mask=[False] * T)
+        part, _ = G(starts[sel].to(DEV), ends[sel].to(DEV), z[sel].to(DEV), target_sequences=seq[sel].to(DEV), tf_mask=[False] * T)
+        assert torch.equal(full[sd], part), 'G rollout: rows of the 4096-row batch vs the same rows as a 512-row batch'
+        real = gmt.trajectory_to_absolute(starts.to(DEV), seq[:, :, :2].to(DEV))
+        dpad = torch.nn.functional.pad(seq[:, :, 2], (1, 0), value=0.05).to(DEV)
+        lp1 = (lengths + 1).to(DEV)
+        state = {k: v.clone() for k, v in D.state_dict().items()}
+        s_full = _critic_pass(D, state, real, dpad, lp1)
+        s_part = _critic_pass(D, state, real[sd], dpad[sd], lp1[sd])
+        assert torch.equal(s_full[sd], s_part), 'D scores: rows of the 4096-row batch vs the same rows as a 512-row batch'
+        D.load_state_dict(state)
+        head, D.output_layers = D.output_layers, torch.nn.Sequential()     # the body alone: the final hidden states (RG.py:776-778)
+        h_full = D(real, dpad, lp1)
+        D.output_layers = head
+    r = slice(0, 8)
+    P64 = {k: H.t(v, torch.float64) for k, v in pg.items()}
+    o_seq = O.generator_forward(P64, starts[r].double(), ends[r].double(), z[r].double(), seq[r].double(), [False] * T)
+    e = [H.relerr(full[r, :, k].cpu(), o_seq[:, :, k]) for k in range(3)]
+    Pd = {k: H.t(v, torch.float64) for k, v in pd.items()}
+    Bd = {k: H.t(v, torch.float64) for k, v in bd.items()}
+    o_s, mid = O.discriminator_forward(Pd, Bd, real[r].cpu().double(), dpad[r].cpu().double(), lengths[r] + 1, training=True,
+                                       return_intermediates=True)
+    e_s, e_h = H.relerr(s_full[r].cpu(), o_s), H.relerr(h_full[r].cpu(), mid['h_combined'])
+    print(f'bf16 at B={B} T={T} H={HID}: rollout vs fp64 oracle dx {e[0]:.1e} dy {e[1]:.1e} dt {e[2]:.1e}; critic final states {e_h:.1e}, '
+          f'scores {e_s:.1e} (oracle scores {o_s.flatten()[:4].tolist()})')
+    assert max(e) <= 5e-2 and e_h <= 3e-2 and e_s <= 5e-2, (e, e_h, e_s)
+
+
+def test_bf16_gradients_are_additive_over_the_batch_at_config3_size():
+    gmt, G, D, pg, pd, bd = _models(7, 8)
+    starts, ends, seq, lengths, z = _batch(2)
+    real = gmt.trajectory_to_absolute(starts.to(DEV), seq[:, :, :2].to(DEV))
+    dpad = torch.nn.functional.pad(seq[:, :, 2], (1, 0), value=0.05).to(DEV)
+    lp1 = (lengths + 1).to(DEV)
+    w = torch.randn(B, 1, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    state = {k: v.clone() for k, v in D.state_dict().items()}
+
+    def grads(rows):
+        D.zero_grad(set_to_none=True)
+        (_critic_pass(D, state, real[rows], dpad[rows], lp1[rows]) * w[rows]).sum().backward()
+        return {k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None}
+
+    g_all = grads(slice(0, B))
+    g_a, g_b = grads(slice(0, B // 2)), grads(slice(B // 2, B))
+    worst = 0.0
+    for k, v in g_all.items():
+        e = H.relerr((g_a[k] + g_b[k]).cpu(), v.cpu())
+        worst = max(worst, e)
+        assert e <= 1e-3, (k, e)
+    print(f'bf16 critic gradients at B={B} L={T + 1} H={HID}: sum over halves vs full batch, worst {worst:.1e}')
