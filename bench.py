@@ -131,7 +131,15 @@ def kernel_table(prof, steps, peak_tflops=PEAK_F32_MFMA_TFLOPS):
     rows = {}
     for k, (n, ms, fl, by) in prof.items():
         r = {'launches_per_step': n / steps, 'ms_per_step': ms / steps, 'avg_launch_ms': ms / n}
-        if fl > 0:
+        if fl > 0 and by > 0:
+            # a call that declares both (the bf16 recurrence steps: as much memory traffic as matrix work) is bounded by the
+            # roof it is nearer to; the other fraction is reported beside it
+            f_m, f_h = fl / (ms * 1e-3) / 1e12 / peak_tflops, by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+            if f_h >= f_m:
+                r.update(bound='hbm', achieved=by / (ms * 1e-3) / 1e9, unit='GB/s', frac=f_h, frac_of_mfma_peak=f_m)
+            else:
+                r.update(bound='mfma', achieved=fl / (ms * 1e-3) / 1e12, unit='TFLOP/s', frac=f_m, frac_of_hbm_peak=f_h)
+        elif fl > 0:
             r.update(bound='mfma', achieved=fl / (ms * 1e-3) / 1e12, unit='TFLOP/s')
             r['frac'] = r['achieved'] / peak_tflops
         elif by > 0:
@@ -156,7 +164,7 @@ def roofline_of_dominant(prof, steps, batch, peak_tflops=PEAK_F32_MFMA_TFLOPS):
             'peak': peak_tflops if r['bound'] == 'mfma' else PEAK_HBM_GBS, 'unit': r['unit'], 'frac': r['frac'],
             'traffic': pmc[0] if pmc else None, 'traffic_unit': f'bytes/launch ({pmc[1]})' if pmc else None,
             'avg_launch_ms': ms / n, 'launches': n,
-            'algorithmic_work_per_launch': (fl if fl > 0 else by) / n,
+            'algorithmic_work_per_launch': (by if r['bound'] == 'hbm' else fl) / n,
             'all_kernels_ms_per_step': {k: v['ms_per_step'] for k, v in rows.items()}}
     return roof, rows
 

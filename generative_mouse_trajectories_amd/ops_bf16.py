@@ -145,7 +145,9 @@ class CriticBodyBf16Fn(torch.autograd.Function):
             h_drop = torch.empty(M, nd * H, device=dev, dtype=BF16) if p_l > 0 else None
             L_.call('gmt_bf16_lstm_layer_fwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_drop), L_.ptr(whh),
                     L_.ptr(lengths), int(ragged), L, B, H, nd, p_l, (int(drop[1]) + l + 1) & 0xFFFFFFFF, L_.stream(),
-                    label='bf16_lstm_fwd', flops=2.0 * (L - 1) * B * nd * 4 * H * H)
+                    label='bf16_lstm_fwd', flops=2.0 * (L - 1) * B * nd * 4 * H * H,
+                    # per row-step-direction: pre 8H + c_prev 4H + h_prev 2H read, gates 8H + c 4H + h 2H (+ dropped h 2H) written
+                    nbytes=float(L) * B * nd * H * (28 + (2 if p_l > 0 else 0)))
             saved_layers.append((x, G, c_all, h_all))
             x = h_drop if p_l > 0 else h_all
         x = h_all
@@ -185,7 +187,9 @@ class CriticBodyBf16Fn(torch.autograd.Function):
             L_.call('gmt_bf16_lstm_layer_bwd', L_.ptr(G), L_.ptr(c_all), L_.ptr(dh_out), L_.ptr(dh_fin), L_.ptr(dcc),
                     L_.ptr(dhc), L_.ptr(whhT), L_.ptr(lengths), int(ragged), L, B, H, nd, p_l,
                     (drop[1] + l + 1) & 0xFFFFFFFF, L_.stream(),
-                    label='bf16_lstm_bwd', flops=2.0 * (L - 1) * B * nd * 4 * H * H)
+                    label='bf16_lstm_bwd', flops=2.0 * (L - 1) * B * nd * 4 * H * H,
+                    # per row-step-direction: gates 8H + dA_next 8H + c 4H + c_prev 4H + dc 4H (+ dh_out 2H) read, dA 8H + dc 4H written
+                    nbytes=float(L) * B * nd * H * (40 + (2 if dh_out is not None else 0)))
             dA = G                                                                             # [M, nd*4H] d(pre-activation)
             if need_lw:
                 p = slab_perm(H, dev)
