@@ -24,3 +24,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 scratch/pmc_table.py /tmp/${tag}_pmck_$c > $out/${tag}_pmc_kernels_$c.txt
   echo "pmc $c (kernels) done"
 done
+# config 3 (bf16, H = 512): bench line + kernel-trace summary + the forward step's fabric traffic
+timeout -k 10 300 python3 bench.py --config 3 --no-cpu-baseline > $out/${tag}_bench_config3.log 2> $out/${tag}_bench_config3.err
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/${tag}_kt3 -- python3 bench.py --config 3 --no-cpu-baseline > $out/${tag}_bench_config3_under_rocprof.log 2> $out/${tag}_rocprof3.err
+python3 tools/prof_summary.py "$(ls /tmp/${tag}_kt3/*/*kernel_trace.csv | head -1)" 9 > $out/${tag}_kernel_stats_config3.txt
+echo "config 3 done"
