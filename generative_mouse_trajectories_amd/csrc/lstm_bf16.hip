@@ -160,6 +160,7 @@ void lstm_step_fwd_kernel(__bf16* __restrict__ G, float* __restrict__ Call, __bf
 // the chip: ndir H/128 B/128 workgroups, two per CU).  The epilogue handles one accumulator block of every wave at a time
 // (a "quarter": 64 rows x 2 slabs), with the saved gates - overwritten by d(pre-activation) - and the two cell-state
 // planes moving through LDS as whole rows; the carried dc (and the thin dh inputs) are read and written directly.
+constexpr int GP2_TQ = 64, GP_BWD_LDS = 3 * (128 + 64) * 128, GP_BWD2_LDS = 3 * (256 + 64) * 128;   // the penalty's step kernels: 72 / 120 KiB rings
 constexpr int BWD_G_OFF = 0, BWD_C_OFF = 64 * 512, BWD_CP_OFF = BWD_C_OFF + 64 * 256;      // 32 + 16 + 16 KiB
 constexpr int BWD_LDS = 72 * 1024;                             // >= the contraction's ring (3 x 24 KiB with 64-row tiles) and the epilogue images
 
@@ -326,7 +327,7 @@ void lstm_step_bwd_gp_kernel(const __bf16* __restrict__ G, __bf16* __restrict__ 
                              const __bf16* __restrict__ WhhT, int L, int B, int H, int ndir, int step, int n_mt, int n_pt)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    using T = Tile<2, 2>;
+    using T = Tile<2, 1>;                                      // 128 units x 64 rows (64 x 64 tiles - 256 workgroups - are no faster)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int d, pt, mt;
@@ -337,14 +338,14 @@ void lstm_step_bwd_gp_kernel(const __bf16* __restrict__ G, __bf16* __restrict__ 
     const bool has_next = step > 0, has_prev = step < L - 1;
     const long long ldg = (long long)ndir * 4 * H, ldh = (long long)ndir * H;
     const long long row0 = (long long)mt * T::TQ;
-    f32x16 acc[2][2];
-    zero_acc<2, 2>(acc);
-    mainloop<2, 2>(WhhT + ((long long)d * H + (long long)pt * T::TP) * 4 * H, 4LL * H,
-                   dA + ((long long)tnext * B + row0) * ldg + (long long)d * 4 * H, ldg, has_next ? 4 * H / BK : 0, lds, acc, wave, lane);
+    f32x16 acc[2][1];
+    zero_acc<2, 1>(acc);
+    mainloop_ring<2, 1, 64, 3>(WhhT + ((long long)d * H + (long long)pt * T::TP) * 4 * H, 4LL * H,
+                               dA + ((long long)tnext * B + row0) * ldg + (long long)d * 4 * H, ldg, has_next ? 4 * H / BK : 0, lds, acc, wave, lane);
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const long long b = row0 + wq * 64 + j * 32 + lo;
+    constexpr int j = 0;
+    {
+        const long long b = row0 + wq * 32 + lo;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -411,7 +412,7 @@ void lstm_step_bwd_gp_kernel(const __bf16* __restrict__ G, __bf16* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(NTHREADS, 2)
+__global__ __launch_bounds__(NTHREADS)
 void lstm_step_bwd2_kernel(const __bf16* __restrict__ PH, const __bf16* __restrict__ G, const float* __restrict__ Call,
                            const float* __restrict__ dct_all, const float* __restrict__ dht_all,
                            __bf16* __restrict__ hhat_all, float* __restrict__ hhat_fin, float* __restrict__ gg_out,
@@ -428,15 +429,15 @@ void lstm_step_bwd2_kernel(const __bf16* __restrict__ PH, const __bf16* __restri
     const int tprev = d == 0 ? t - 1 : t + 1;                  // previous step of this sweep = the forward pass's predecessor
     const bool has_prev = step > 0;
     const long long ldg = (long long)ndir * 4 * H, ldh = (long long)ndir * H;
-    const long long row0 = (long long)mt * FWD_TQ;
-    f32x16 acc[4][2];
-    zero_acc<4, 2>(acc);
-    mainloop_ring<4, 2, 32, FWD_NST>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H,
-                     hhat_all + ((long long)tprev * B + row0) * ldh + (long long)d * H, ldh, has_prev ? H / 32 : 0, lds, acc, wave, lane);
+    const long long row0 = (long long)mt * GP2_TQ;              // 256 gate columns x 64 rows
+    f32x16 acc[4][1];
+    zero_acc<4, 1>(acc);
+    mainloop_ring<4, 1, 64, 3>(Whh + ((long long)d * 4 * H + (long long)pt * TP) * H, H,
+                               hhat_all + ((long long)tprev * B + row0) * ldh + (long long)d * H, ldh, has_prev ? H / BK : 0, lds, acc, wave, lane);
     const int wp = wave >> 1, wq = wave & 1, lo = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const long long b = row0 + wq * 64 + j * 32 + lo;
+    constexpr int j = 0;
+    {
+        const long long b = row0 + wq * 32 + lo;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int un = pt * 64 + wp * 32 + 8 * g4 + 4 * hi;
@@ -557,14 +558,14 @@ extern "C" int gmt_bf16_lstm_layer_bwd_gp(const void* gates, void* dA, const flo
                                           const float* gg_in, const float* gc_in, float* dct_all, float* dht_all,
                                           float* dc_carry, const void* w_hhT, int L, int B, int H, int ndir, hipStream_t stream)
 {
-    using T = Tile<2, 2>;
+    using T = Tile<2, 1>;
     GMT_CHECK_ARG(gates && dA && c_all && dh_fin && dc_carry && w_hhT && L >= 1 && (ndir == 1 || ndir == 2));
     GMT_CHECK_ARG(B > 0 && B % 256 == 0 && H > 0 && H % T::TP == 0 && (dct_all == nullptr) == (dht_all == nullptr));
     const int n_mt = B / T::TQ, n_pt = H / T::TP;
-    if (hipFuncSetAttribute((const void*)lstm_step_bwd_gp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)lstm_step_bwd_gp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GP_BWD_LDS) != hipSuccess)
         return GMT_ERR_HIP;
     for (int step = 0; step < L; ++step)
-        hipLaunchKernelGGL(lstm_step_bwd_gp_kernel, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), T::LDS_BYTES, stream,
+        hipLaunchKernelGGL(lstm_step_bwd_gp_kernel, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), GP_BWD_LDS, stream,
                            (const __bf16*)gates, (__bf16*)dA, c_all, (const __bf16*)dh_out, dh_fin, gg_in, gc_in, dct_all, dht_all,
                            dc_carry, (const __bf16*)w_hhT, L, B, H, ndir, step, n_mt, n_pt);
     GMT_LAUNCH_CHECK();
@@ -577,11 +578,11 @@ extern "C" int gmt_bf16_lstm_layer_bwd2(const void* pre_hat, const void* gates, 
 {
     GMT_CHECK_ARG(pre_hat && gates && c_all && dct_all && dht_all && hhat_all && hhat_fin && g_gates && g_c && chat_carry && w_hh);
     GMT_CHECK_ARG(L >= 1 && (ndir == 1 || ndir == 2) && B > 0 && B % 256 == 0 && H > 0 && (4 * H) % TP == 0 && H % BK == 0);
-    const int n_mt = B / FWD_TQ, n_pt = 4 * H / TP;
-    if (hipFuncSetAttribute((const void*)lstm_step_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS) != hipSuccess)
+    const int n_mt = B / GP2_TQ, n_pt = 4 * H / TP;
+    if (hipFuncSetAttribute((const void*)lstm_step_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GP_BWD2_LDS) != hipSuccess)
         return GMT_ERR_HIP;
     for (int step = 0; step < L; ++step)
-        hipLaunchKernelGGL(lstm_step_bwd2_kernel, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), FWD_LDS, stream,
+        hipLaunchKernelGGL(lstm_step_bwd2_kernel, dim3(ndir * n_mt * n_pt), dim3(NTHREADS), GP_BWD2_LDS, stream,
                            (const __bf16*)pre_hat, (const __bf16*)gates, c_all, dct_all, dht_all, (__bf16*)hhat_all, hhat_fin,
                            g_gates, g_c, chat_carry, (const __bf16*)w_hh, L, B, H, ndir, step, n_mt, n_pt);
     GMT_LAUNCH_CHECK();
