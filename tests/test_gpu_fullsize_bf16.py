@@ -116,3 +116,22 @@ def test_bf16_gradients_are_additive_over_the_batch_at_config3_size():
         worst = max(worst, e)
         assert e <= 1e-3, (k, e)
     print(f'bf16 critic gradients at B={B} L={T + 1} H={HID}: sum over halves vs full batch, worst {worst:.1e}')
+
+
+def test_bf16_generator_sampling_batch_uses_the_wide_head_tile():
+    """At sampling-sized batches (B / 128 >= 512 row tiles) the rollout's head runs on 128-row tiles (gen_head_kernel<2>) instead
+    of the 64-row tiles of a training batch: 65 536 rows for 3 steps, three 256-row blocks against the same rows run as a 256-row batch (the two
+    instantiations fuse the head's fp32 dot products differently: equal to 1e-5, not bit for bit)."""
+    gmt, G, D, pg, pd, bd = _models(9, 10)
+    Bs, Ts = 65536, 3
+    g = torch.Generator().manual_seed(4)
+    starts, ends = torch.rand(Bs, 2, generator=g).to(DEV), torch.rand(Bs, 2, generator=g).to(DEV)
+    z = torch.randn(Bs, OVER['latent_dim'], generator=g).to(DEV)
+    seq = torch.zeros(Bs, Ts, 3, device=DEV)
+    with torch.no_grad():
+        full, _ = G(starts, ends, z, target_sequences=seq, tf_mask=[False] * Ts)
+        for r0 in (0, 256 * 77, Bs - 256):
+            r = slice(r0, r0 + 256)
+            part, _ = G(starts[r], ends[r], z[r], target_sequences=seq[r], tf_mask=[False] * Ts)
+            H.assert_close(full[r], part, 1e-5, f'rows {r0}..: 128-row head tiles vs 64-row head tiles')
+    assert bool(torch.isfinite(full).all())
