@@ -368,9 +368,10 @@ int gmt_bf16_lstm_layer_bwd(void* gates, const float* c_all, const void* dh_out,
  * stays in order for the caller.  The workgroups of one launch move in lock-step (contraction, then the HBM-heavy epilogue);
  * two chains overlap one's epilogue and launch boundary with the other's MFMAs.  Results do not depend on n (bit-identical).
  * n = 1 or 2 (default 2, or the environment's GMT_BF16_ROW_GROUPS); a call uses one chain when B / 2 is not a multiple of four
- * row tiles.  The library deliberately owns ONE extra stream per device: a process has GPU_MAX_HW_QUEUES (4) hardware queues
- * per priority, and with three library streams alive a later two-stream sequence of the fp32 path
- * (Trainer.overlap_g_forward's high-priority torch stream) never completed on this stack.
+ * row tiles.  The library deliberately owns ONE extra stream per device: a process has GPU_MAX_HW_QUEUES (4) hardware queues,
+ * and once default-priority streams fill them (three library streams + the default stream) a later two-stream sequence of
+ * the fp32 path (Trainer.overlap_g_forward's high-priority torch stream) never completes on this stack; with
+ * GPU_MAX_HW_QUEUES=8 it does.
  * With n = 2 these calls must not be made under single-stream HIP graph capture. */
 int gmt_bf16_set_row_groups(int n);
 
