@@ -11,7 +11,8 @@ namespace gmt_bf16 {
 // the contraction, then all in the HBM-heavy epilogue), two chains drift apart and one's epilogue runs under the other's
 // MFMAs; a chain's launch boundary is covered by the other chain as well.  The side streams are the library's own (one
 // set per device, created on first use), forked from and joined to the caller's stream with events, so the caller sees
-// an ordinary in-order call.
+// an ordinary in-order call.  The fork / join events are per device too: layer calls on ONE device are expected from one
+// host thread at a time (as autograd issues them); MAX_GROUPS stays at 2 for the reason given in include/gmt_hip.h.
 constexpr int MAX_GROUPS = 2, MAX_DEVICES = 64;
 struct side_streams { hipStream_t s[MAX_GROUPS - 1]; hipEvent_t fork, join[MAX_GROUPS - 1]; int n; };
 
@@ -73,6 +74,5 @@ int run_row_groups(int ng, int L, hipStream_t stream, F launch)
     }
     return GMT_OK;
 }
-
 
 }  // namespace gmt_bf16
