@@ -18,8 +18,13 @@ from . import _lib as L_
 TM = 32  # trajectories per workgroup tile (csrc/lstm_tile.h GMT_TM)
 
 
-def pad_rows(n: int) -> int:
-    return (n + TM - 1) // TM * TM
+def pad_rows(n: int, tile: int = TM) -> int:
+    return (n + tile - 1) // tile * tile
+
+
+def row_tile(config) -> int:
+    """Rows every batch is padded to a multiple of: 32 for the fp32 kernels, 256 for the bf16 family (ops_bf16.ROW_TILE)."""
+    return 256 if getattr(config, 'compute_dtype', 'fp32') == 'bf16' else TM
 
 
 # ----------------------------------------------------------------------------------------

@@ -482,7 +482,7 @@ class Trainer:
         self.d_optimizer.zero_grad()
         starts, ends, sequences, lengths = self._to_dev(real_batch)
         batch_size, T = sequences.shape[0], sequences.shape[1]
-        Bp = ops.pad_rows(batch_size)
+        Bp = ops.pad_rows(batch_size, ops.row_tile(self.config))
         G, D = self.generator, self.discriminator
         # real_trajectories / real_dts_padded of RG.py:931-934, straight into the kernels' time-major padded layout
         real_pos, real_dts = ops.traj_from_seq(sequences.float(), starts, False, batch_size, Bp)
@@ -530,7 +530,7 @@ class Trainer:
         self.g_optimizer.zero_grad()
         starts, ends, sequences, lengths = self._to_dev(real_batch)
         batch_size, T = sequences.shape[0], sequences.shape[1]
-        Bp = ops.pad_rows(batch_size)
+        Bp = ops.pad_rows(batch_size, ops.row_tile(self.config))
         G, D = self.generator, self.discriminator
         tf_ratio = self.get_teacher_forcing_ratio()
         tf_mask = noise.get('tf_mask')

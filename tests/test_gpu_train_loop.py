@@ -97,3 +97,51 @@ def test_reference_style_checkpoint_into_trainer(tmp_path):
     batch = gmt.collate_trajectories([ds[i] for i in range(8)])
     m = tr.train_discriminator_step(batch)
     assert all(np.isfinite(v) for v in m.values())
+
+
+def test_run_loop_on_a_recording_at_config3_width_bf16(tmp_path, capsys):
+    """The same run loop with compute_dtype = 'bf16' and both networks at H = 512 (BASELINE configs[2]'s width) on the recording
+    (ragged batches of 8 trajectories, padded to the kernels' 256 rows; gradient penalty every 2nd D step; both dropouts on):
+    two epochs, finite parameters, a checkpoint that resumes to the same step - the step functions' numbers are
+    tests/test_gpu_bf16.py's."""
+    import generative_mouse_trajectories_amd as gmt
+    cfg = _cfg(gmt)
+    cfg.generator_hidden_dim = cfg.discriminator_hidden_dim = 512
+    cfg.compute_dtype = 'bf16'
+    ds = gmt.MouseTrajectoryDataset(SAMPLE, cfg)
+    loader = DataLoader(ds, batch_sampler=gmt.LengthBucketedBatchSampler.from_dataset(ds, cfg.batch_size, seed=2),
+                        collate_fn=gmt.collate_trajectories)
+    torch.manual_seed(0)
+    tr = gmt.Trainer(gmt.Generator(cfg), gmt.Discriminator(cfg), cfg, DEV, log_dir=str(tmp_path / 'runs'))
+    ck = tmp_path / 'ck'
+    tr.train(loader, num_epochs=2, checkpoint_dir=str(ck))
+    out = capsys.readouterr().out
+    assert 'Epoch 1/2' in out and 'Training complete!' in out
+    assert (ck / 'checkpoint_epoch_0.pt').exists()
+    assert tr.d_step == 2 * 3 * cfg.n_critic
+    for p in list(tr.generator.parameters()) + list(tr.discriminator.parameters()):
+        assert torch.isfinite(p).all()
+    path = str(tmp_path / 'now.pt')
+    tr.save_checkpoint(path)
+    torch.manual_seed(1)
+    tr2 = gmt.Trainer(gmt.Generator(cfg), gmt.Discriminator(cfg), cfg, DEV, log_dir=str(tmp_path / 'runs2'))
+    tr2.load_checkpoint(path)
+    tr2.d_step = tr.d_step
+    batch = gmt.collate_trajectories([ds[i] for i in range(8)])
+    B, T = batch['sequences'].shape[:2]
+    g = torch.Generator().manual_seed(9)
+    noise_d = {'z': torch.randn(B, cfg.latent_dim, generator=g), 'gp_idx': torch.randperm(B, generator=g),
+               'alpha': torch.rand(2, 1, 1, generator=g)}
+    noise_g = {'z': torch.randn(B, cfg.latent_dim, generator=g), 'tf_mask': [True, False] * (T // 2) + [False] * (T % 2)}
+    cfg.lstm_dropout = 0.0
+    for t_ in (tr, tr2):
+        t_.generator.train(); t_.discriminator.train()
+        t_.discriminator.output_layers[2].p = 0.0
+    m1 = (tr.train_discriminator_step(batch, noise_d), tr.train_generator_step(batch, noise_g))
+    m2 = (tr2.train_discriminator_step(batch, noise_d), tr2.train_generator_step(batch, noise_g))
+    assert m1 == m2, (m1, m2)
+    assert torch.equal(tr.g_flat.flat, tr2.g_flat.flat) and torch.equal(tr.d_flat.flat, tr2.d_flat.flat)
+    # sampling through the bf16 rollout (RG.py:606-690)
+    starts, ends = batch['starts'].to(DEV), batch['ends'].to(DEV)
+    traj, lens = tr.generator.generate(starts, ends)
+    assert traj.shape[0] == B and bool(torch.isfinite(traj).all()) and int(lens.min()) >= 1
