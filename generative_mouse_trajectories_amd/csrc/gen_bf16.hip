@@ -378,25 +378,45 @@ void gen_bwd_book_kernel(book_args a)
         for (int i = threadIdx.x; i < G4; i += NTHREADS)
             *reinterpret_cast<bf16x8*>(wus + i * 8) = *reinterpret_cast<const bf16x8*>(a.w_u + (long long)i * 8);
     __syncthreads();
-    for (int rr = 0; rr < 4; ++rr) {
-        const long long row = (long long)(a.blk0 + blockIdx.x) * 16 + wave * 4 + rr;
-        float du[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (a.da0_next) {
-            const __bf16* dr = a.da0_next + row * G4;
-            for (int c = 0; c < G4 / 512; ++c) {                // 512 columns per pass: 8 per lane
-                const int k0 = c * 512 + lane * 8;
-                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dr + k0);
+    // du_{t+1} = da0_{t+1} W_u for the wave's 4 rows at once: all 16 row segments are requested before any is used (one exposed
+    // memory latency instead of four), and every W_u row read from the LDS serves the 4 rows
+    float du4[4][7];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const bf16x8 w = *reinterpret_cast<const bf16x8*>(wus + (k0 + e) * 8);
-                    const float x = (float)dv[e];
+    for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                    for (int s2 = 0; s2 < 7; ++s2) du[s2] += x * (float)w[s2];
+        for (int s2 = 0; s2 < 7; ++s2) du4[rr][s2] = 0.f;
+    if (a.da0_next) {
+        constexpr int NPASS = 4;                                // 4H / 512 with H = 512 (checked by the entry point)
+        const long long rowb = (long long)(a.blk0 + blockIdx.x) * 16 + wave * 4;
+        bf16x8 dv[4][NPASS];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int c = 0; c < NPASS; ++c)
+                dv[rr][c] = *reinterpret_cast<const bf16x8*>(a.da0_next + (rowb + rr) * G4 + c * 512 + lane * 8);
+#pragma unroll
+        for (int c = 0; c < NPASS; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bf16x8 w = *reinterpret_cast<const bf16x8*>(wus + (c * 512 + lane * 8 + e) * 8);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float x = (float)dv[rr][c][e];
+#pragma unroll
+                    for (int s2 = 0; s2 < 7; ++s2) du4[rr][s2] += x * (float)w[s2];
                 }
             }
 #pragma unroll
-            for (int s2 = 0; s2 < 7; ++s2) du[s2] = gmt_wave_sum(du[s2]);
-        }
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int s2 = 0; s2 < 7; ++s2) du4[rr][s2] = gmt_wave_sum(du4[rr][s2]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const long long row = (long long)(a.blk0 + blockIdx.x) * 16 + wave * 4 + rr;
+        float du[7];
+#pragma unroll
+        for (int s2 = 0; s2 < 7; ++s2) du[s2] = du4[rr][s2];
         // gradient of the position before step t+1: through the dynamic features of step t+1, plus what flows on (RG.py:502-504, 585)
         float px = 0.f, py = 0.f;
         if (a.da0_next) {
