@@ -26,6 +26,21 @@ int main(int argc, char** argv)
     CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("B=%d: %.1f us per step\n", B, ms * 1e3 / L);
+    {   // the backward sweep over the same buffers (gates are overwritten with d(pre-activation)): timing, and for the PMC passes
+        void* dhout; float *dhfin, *dcc, *dhc; void* whhT;
+        CK(hipMalloc(&dhout, (size_t)L * B * ndir * H * 2)); CK(hipMemset(dhout, 0, (size_t)L * B * ndir * H * 2));
+        CK(hipMalloc(&dhfin, (size_t)ndir * B * H * 4)); CK(hipMemset(dhfin, 0, (size_t)ndir * B * H * 4));
+        CK(hipMalloc(&dcc, (size_t)ndir * B * H * 4)); CK(hipMalloc(&dhc, (size_t)ndir * B * H * 4));
+        CK(hipMalloc(&whhT, (size_t)ndir * 4 * H * H * 2)); CK(hipMemset(whhT, 0, (size_t)ndir * 4 * H * H * 2));
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0, st));
+            int rc = gmt_bf16_lstm_layer_bwd(gates, call, dhout, dhfin, dcc, dhc, whhT, nullptr, 0, L, B, H, ndir, 0.1f, 5u, st);
+            if (rc) { printf("bwd rc %d\n", rc); return 1; }
+            CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        printf("backward: %.1f us per step\n", ms * 1e3 / L);
+    }
     std::vector<long long> buf(4096 * 16);
     CK(hipMemcpyFromSymbol(buf.data(), HIP_SYMBOL(gmt_phase_buf), buf.size() * 8));
     const int nb = std::min(4096, ndir * (B / 128) * 8);
