@@ -1,8 +1,8 @@
 // Building blocks of the bf16-operand / fp32-accumulate kernels (BASELINE config 3: H = 512, where the recurrent
 // weights no longer fit a CU and the gate contractions are real dense GEMMs).
 //
-// One tile shape serves every kernel of this family: a workgroup of 4 waves computes
-//     D[p][q] = sum_k P[p][k] * Q[q][k]          256 (p) x 256 (q), K in steps of 64
+// One contraction form serves every kernel of this family: a workgroup of 4 or 8 waves computes a tile of
+//     D[p][q] = sum_k P[p][k] * Q[q][k]          (64 NPB) x (32 NQB NWQ), K in steps of 32 or 64
 // with both operands K-CONTIGUOUS in memory (weights [N][K], activations [M][K]) - "NT" in BLAS terms.  P feeds the
 // MFMA's A side and Q its B side, so in the 32x32 accumulator tile (cdna_hip_programming.md section 3)
 //     lane l, register r  holds  D[p = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][q = l & 31]:
@@ -10,13 +10,15 @@
 // the activation rows (trajectory-steps) on Q, so an epilogue thread owns one trajectory row and 4 consecutive
 // output columns at a time: 8-byte bf16 / 16-byte fp32 accesses, per-row masks are per-lane scalars.
 //
-// Staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers), two LDS buffers of
-// (256 + 256) rows x 128 B, one barrier per K-tile ("glds, 2 LDS buffers, BK = 64" of the programming guide).  The
-// LDS image of a tile is [row][8 chunks of 16 B]; chunk c of row r is stored at position c ^ ((r >> 1) & 7) - the
-// DMA destination is lane-linear, so the XOR is applied to the per-lane SOURCE address - which makes the
-// ds_read_b128 fragment reads (16-lane groups {0-3,12-15,20-27}, ...) conflict-free.
-// Wave (wp, wq) = (wave >> 1, wave & 1) owns P rows [128 wp, +128) x Q rows [128 wq, +128): 4 x 4 accumulator tiles
-// (256 VGPRs), 8 fragment reads per 16 MFMAs.
+// Staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers).  Two loops share the image format:
+//   mainloop       (the GEMMs): two LDS buffers of (TP + TQ) rows x 128 B, one barrier per 64-deep K-tile, the next tile's DMA
+//                  issued in one burst after the barrier ("glds, 2 LDS buffers, BK = 64" of the programming guide);
+//   mainloop_ring  (the per-timestep kernels): three slots of 32- or 64-deep K-tiles, counted vmcnt waits, the DMA pieces
+//                  spread behind the MFMA clusters.
+// The LDS image of a tile is [row][chunks of 16 B]; chunk c of row r is stored at position c ^ ((r >> 1) & 7) (64-deep) or
+// c ^ ((r >> 2) & 3) (32-deep) - the DMA destination is lane-linear, so the XOR is applied to the per-lane SOURCE address -
+// which makes the ds_read_b128 fragment reads (16-lane groups {0-3,12-15,20-27}, ...) conflict-free.
+// Wave (wp, wq) owns P rows [TP/2 wp, +TP/2) x a Q row block: NPB x NQB accumulator tiles of 32 x 32.
 #pragma once
 #include "gmt_common.h"
 #include "bf16_maps.h"
@@ -113,63 +115,6 @@ __device__ __forceinline__ void mainloop(const __bf16* __restrict__ Pg, long lon
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[s & 1][i], qf[s & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// The same contraction with 32-deep K tiles (two LDS buffers of half the size): for kernels that want TWO workgroups per CU,
-// so that one's epilogue (HBM traffic) runs under the other's MFMAs.  4 waves (2 x 2), tile (64 NPB) x (64 NQB).
-template <int ROWS>
-__device__ __forceinline__ void stage32(const __bf16* __restrict__ g, long long ld, char* lds_tile, int wave, int lane)
-{
-#pragma unroll
-    for (int j = 0; j < ROWS / 64; ++j) {
-        const int row = j * 64 + wave * 16 + (lane >> 2);
-        const int chunk = gmt_bf16_maps::stage32_src_chunk(row, lane & 3);
-        const __bf16* src = g + (long long)row * ld + chunk * 8;
-        char* dst = lds_tile + (j * 64 + wave * 16) * 64;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-}
-
-template <int NPB, int NQB>
-__device__ __forceinline__ void mainloop32(const __bf16* __restrict__ Pg, long long ldp, const __bf16* __restrict__ Qg,
-                                           long long ldq, int nk32, char* lds, f32x16 (&acc)[NPB][NQB], int wave, int lane)
-{
-    constexpr int TPr = 64 * NPB, TQr = 64 * NQB, STG = (TPr + TQr) * 64;
-    const int wp = wave >> 1, wq = wave & 1;
-    const int lo = lane & 31, hi = lane >> 5;
-    if (nk32 > 0) {
-        stage32<TPr>(Pg, ldp, lds, wave, lane);
-        stage32<TQr>(Qg, ldq, lds + TPr * 64, wave, lane);
-    }
-    for (int t = 0; t < nk32; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const char* cur = lds + (t & 1) * STG;
-        if (t + 1 < nk32) {
-            char* nxt = lds + ((t + 1) & 1) * STG;
-            stage32<TPr>(Pg + (long long)(t + 1) * 32, ldp, nxt, wave, lane);
-            stage32<TQr>(Qg + (long long)(t + 1) * 32, ldq, nxt + TPr * 64, wave, lane);
-        }
-        const char* pt = cur + (wp * (TPr / 2) + lo) * 64;
-        const char* qt = cur + TPr * 64 + (wq * (TQr / 2) + lo) * 64;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int off = gmt_bf16_maps::stage32_addr(lo, 2 * s + hi) - lo * 64;
-            bf16x8 pf[NPB], qf[NQB];
-#pragma unroll
-            for (int i = 0; i < NPB; ++i) pf[i] = *reinterpret_cast<const bf16x8*>(pt + i * 32 * 64 + off);
-#pragma unroll
-            for (int j = 0; j < NQB; ++j) qf[j] = *reinterpret_cast<const bf16x8*>(qt + j * 32 * 64 + off);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < NPB; ++i)
-#pragma unroll
-                for (int j = 0; j < NQB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
         }
     }
 }
