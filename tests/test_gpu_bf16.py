@@ -28,7 +28,7 @@ def _L():
 def test_bf16_gemm_epilogues_vs_torch():
     from generative_mouse_trajectories_amd import ops_bf16 as OB
     g = torch.Generator(device='cuda').manual_seed(1)
-    for (M, N, K) in [(256, 256, 64), (512, 768, 192), (1024, 2048, 512)]:
+    for (M, N, K) in [(256, 256, 64), (512, 768, 192), (1024, 2048, 512), (512, 512, 2048), (256, 768, 4096)]:   # K >= 2048: the 4-wave loop
         A = torch.randn(M, K, device=DEV, generator=g).to(BF)
         W = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(BF)
         b = torch.randn(N, device=DEV, generator=g)
