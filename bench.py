@@ -289,6 +289,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='run the two generator rollouts of an iteration one after the other')
     ap.add_argument('--cpu-threads', type=int, default=16)
+    ap.add_argument('--sync-metrics', action='store_true',
+                    help='block on the metrics read-back inside every step function (the reference\'s .item() behaviour)')
     args = ap.parse_args()
     args.steps_given, args.warmup_given = args.steps is not None, args.warmup is not None
     if args.steps is None:
@@ -335,14 +337,18 @@ def main():
     tf_mask = [False] * T_STEPS                     # same host decisions on every rank
 
     host = {'d_enqueue': 0.0, 'd_wait': 0.0, 'g_enqueue': 0.0, 'g_wait': 0.0}
+    if args.sync_metrics:
+        tr.max_steps_in_flight = 0                  # every step function blocks on its own metrics like the reference's .item()
+    metrics = []
 
     def one_step():
-        # host-side split of a step: time to ENQUEUE it (Python + launches) vs time blocked in the metrics read-back
+        # host-side split of a step: time to ENQUEUE it (Python + launches) vs time blocked inside the step function
+        # after that (the metrics read-back with --sync-metrics; else only the bound on steps in flight)
         tr.host_clock = clk = []
         t0 = time.perf_counter()
-        tr.train_discriminator_step(batch)
+        metrics.append(tr.train_discriminator_step(batch))
         t1 = time.perf_counter()
-        tr.train_generator_step(batch, {'tf_mask': tf_mask})
+        metrics.append(tr.train_generator_step(batch, {'tf_mask': tf_mask}))
         t2 = time.perf_counter()
         host['d_enqueue'] += clk[0][1] - t0; host['d_wait'] += t1 - clk[0][1]
         host['g_enqueue'] += clk[1][1] - t1; host['g_wait'] += t2 - clk[1][1]
@@ -375,9 +381,12 @@ def main():
         host[k] = 0.0
     _lib.profile_start(only=[dominant])
     t0 = time.perf_counter()
+    del metrics[:]
     for _ in range(args.steps):
         one_step()
     barrier()
+    # every step's metrics are READ inside the timed region (what a training loop does with them at the latest)
+    last = [dict(m) for m in metrics][-2:]
     dt = time.perf_counter() - t0
     prof = _lib.profile_stop()
     if world > 1:
@@ -411,6 +420,9 @@ def main():
             'roofline': roof,
             'kernels': rows,
             'host_ms_per_step': {k: v / args.steps * 1e3 for k, v in host.items()},
+            'metrics_readback': 'blocking per step (--sync-metrics)' if args.sync_metrics else
+                                f'asynchronous (StepMetrics; at most {tr.max_steps_in_flight} step calls in flight), all read inside the timed region',
+            'last_step_metrics': {k: v for m in last for k, v in m.items()},
             'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated() / 1e9,
         }
         if world == 1 and not args.no_cpu_baseline:

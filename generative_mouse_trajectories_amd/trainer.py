@@ -278,6 +278,53 @@ def dp_tf_coins(tf_seed: int, g_step: int, T: int, tf_ratio: float) -> List[bool
     return [bool(v) for v in (torch.rand(T, generator=g) < tf_ratio).tolist()]
 
 
+class StepMetrics(dict):
+    """The dict of floats a step function returns (RG.py:1024-1029, 1112-1118) - same keys, same values - whose
+    numbers are still on their way from the GPU when the function returns: the step's scalars are copied into
+    pinned host memory by the stream (one asynchronous copy, one event) and the dict fills itself in at the first
+    READ of any value.  The reference ends every step in 4-5 blocking `.item()` calls; here the host goes on to
+    enqueue the next step while the GPU finishes this one, so the command queue never runs dry at a step boundary
+    (profiles/r3_01_gap_table.txt: the blocking read-back left the GPU idle for the head of every step).
+    Reading is what synchronises: `m['d_loss']`, `m.items()`, `dict(m)`, `json.dumps(m)`, `print(m)` all wait for
+    the step's event first.  Keys, len() and `in` are known at once."""
+
+    def __init__(self, keys, host_buf: torch.Tensor, event, extra: Optional[Dict[str, float]] = None):
+        super().__init__({k: None for k in keys})
+        if extra:
+            super().update(extra)
+        self._pending = (tuple(keys), host_buf, event)
+
+    @property
+    def ready(self) -> bool:
+        return self._pending is None or self._pending[2].query()
+
+    def wait(self) -> 'StepMetrics':
+        if self._pending is not None:
+            keys, buf, ev = self._pending
+            ev.synchronize()
+            self._pending = None
+            for k, v in zip(keys, buf.tolist()):
+                super().__setitem__(k, v)
+        return self
+
+    # every way of reading a value goes through wait(); __iter__ / keys are overridden as well so that dict(m),
+    # {**m} and json.dumps take the generic mapping path instead of copying the raw table
+    def __getitem__(self, k): return dict.__getitem__(self.wait(), k)
+    def get(self, k, default=None): return dict.get(self.wait(), k, default)
+    def items(self): return dict.items(self.wait())
+    def values(self): return dict.values(self.wait())
+    def keys(self): return dict.keys(self.wait())
+    def __iter__(self): return dict.__iter__(self.wait())
+    def __repr__(self): return dict.__repr__(self.wait())
+    def __eq__(self, other): return dict.__eq__(self.wait(), other)
+    def __ne__(self, other): return dict.__ne__(self.wait(), other)
+    def copy(self): return dict(self.wait())
+    def pop(self, *a): return dict.pop(self.wait(), *a)
+    def setdefault(self, *a): return dict.setdefault(self.wait(), *a)
+    def __reduce__(self): return (dict, (dict(self.wait()),))
+    __hash__ = None
+
+
 class _NullWriter:
     def add_scalar(self, *a, **k): pass
     def add_figure(self, *a, **k): pass
@@ -384,6 +431,10 @@ class Trainer:
         self._spec = None
         self._g_version = 0
         self.host_clock = None         # a list: the step functions append (tag, perf_counter()) when a step is fully enqueued
+        # step functions return StepMetrics whose floats arrive asynchronously; the host may run at most this many
+        # step-function calls ahead of the GPU (0: every step function blocks on its own read-back like the reference)
+        self.max_steps_in_flight = 4
+        self._in_flight: List[StepMetrics] = []
         self.sync_replicas()
 
     # ---- helpers ---------------------------------------------------------------------
@@ -437,6 +488,19 @@ class Trainer:
         else:
             loss.backward()
             flat.gather_grads()
+
+    def _metrics(self, keys, scalars: List[torch.Tensor], extra: Optional[Dict[str, float]] = None) -> StepMetrics:
+        """The step's device scalars -> one pinned-memory copy on the stream + an event; see StepMetrics."""
+        dev_vals = torch.stack([s_.detach().float().reshape(()) for s_ in scalars])
+        host = torch.empty(len(scalars), dtype=torch.float32, pin_memory=True)
+        host.copy_(dev_vals, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        m = StepMetrics(keys, host, ev, extra)
+        self._in_flight.append(m)
+        while len(self._in_flight) > max(0, int(self.max_steps_in_flight)):
+            self._in_flight.pop(0).wait()
+        return m
 
     def _to_dev(self, batch: Dict):
         d = self.device
@@ -520,8 +584,8 @@ class Trainer:
         self.d_optimizer.step()
         if self.host_clock is not None:
             self.host_clock.append(('d_enqueued', __import__('time').perf_counter()))
-        vals = torch.stack([d_loss.detach(), gp.detach(), real_score.detach().mean(), fake_score.detach().mean()]).tolist()
-        return {'d_loss': vals[0], 'd_gp': vals[1], 'd_real_score': vals[2], 'd_fake_score': vals[3]}
+        return self._metrics(('d_loss', 'd_gp', 'd_real_score', 'd_fake_score'),
+                             [d_loss, gp, real_score.detach().mean(), fake_score.detach().mean()])
 
     # ---- generator step (RecurrentGAN.py:1031-1118) ---------------------------------
     def train_generator_step(self, real_batch: Dict, noise: Optional[Dict] = None) -> Dict[str, float]:
@@ -582,10 +646,9 @@ class Trainer:
         self._g_version += 1
         if self.host_clock is not None:
             self.host_clock.append(('g_enqueued', __import__('time').perf_counter()))
-        vals = torch.stack([g_loss.detach(), endpoint_loss.detach(), direction_loss.detach(),
-                            fake_score.detach().mean()]).tolist()
-        return {'g_loss': vals[0], 'g_endpoint_loss': vals[1], 'g_direction_loss': vals[2],
-                'g_fake_score': vals[3], 'teacher_forcing_ratio': tf_ratio}
+        return self._metrics(('g_loss', 'g_endpoint_loss', 'g_direction_loss', 'g_fake_score'),
+                             [g_loss, endpoint_loss, direction_loss, fake_score.detach().mean()],
+                             {'teacher_forcing_ratio': tf_ratio})
 
     # ---- epoch / run loop (RecurrentGAN.py:1120-1303) -------------------------------
     def train_epoch(self, dataloader: Iterable) -> Dict[str, float]:
@@ -594,12 +657,13 @@ class Trainer:
         keys = ['d_loss', 'd_gp', 'd_real_score', 'd_fake_score', 'g_loss', 'g_endpoint_loss',
                 'g_direction_loss', 'g_fake_score']
         epoch_metrics: Dict[str, List[float]] = {k: [] for k in keys}
+        steps: List[Dict[str, float]] = []
         for batch in dataloader:
             for _ in range(self.config.n_critic):
-                for k, v in self.train_discriminator_step(batch).items():
-                    if k in epoch_metrics:
-                        epoch_metrics[k].append(v)
-            for k, v in self.train_generator_step(batch).items():
+                steps.append(self.train_discriminator_step(batch))
+            steps.append(self.train_generator_step(batch))
+        for m in steps:                                # read after the loop: the step functions never wait on the GPU
+            for k, v in m.items():
                 if k in epoch_metrics:
                     epoch_metrics[k].append(v)
         avg = {k: float(np.mean(v)) for k, v in epoch_metrics.items() if v}
@@ -657,6 +721,9 @@ class Trainer:
         self.g_optimizer.load_state_dict(checkpoint['g_optimizer_state_dict'])
         self.d_optimizer.load_state_dict(checkpoint['d_optimizer_state_dict'])
         self.best_loss = checkpoint.get('best_loss', float('inf'))
+        # the data-parallel teacher-forcing coins are a function of (tf_seed, generator step index): the index is not
+        # a checkpoint key (the file layout is the reference's), the restored Adam state carries it
+        self._g_step = self.g_optimizer.step_count
         ops.weights_changed()
         self.sync_replicas()
         print(f'Loaded checkpoint from epoch {self.epoch}')
