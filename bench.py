@@ -289,6 +289,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='run the two generator rollouts of an iteration one after the other')
     ap.add_argument('--cpu-threads', type=int, default=16)
+    ap.add_argument('--no-real-overlap', action='store_true',
+                    help='do not launch the next D step\'s real-sample critic forward beside the G step\'s BPTT kernel')
     ap.add_argument('--sync-metrics', action='store_true',
                     help='block on the metrics read-back inside every step function (the reference\'s .item() behaviour)')
     args = ap.parse_args()
@@ -348,7 +350,7 @@ def main():
         t0 = time.perf_counter()
         metrics.append(tr.train_discriminator_step(batch))
         t1 = time.perf_counter()
-        metrics.append(tr.train_generator_step(batch, {'tf_mask': tf_mask}))
+        metrics.append(tr.train_generator_step(batch, {'tf_mask': tf_mask}, next_batch=None if args.no_real_overlap else batch))
         t2 = time.perf_counter()
         host['d_enqueue'] += clk[0][1] - t0; host['d_wait'] += t1 - clk[0][1]
         host['g_enqueue'] += clk[1][1] - t1; host['g_wait'] += t2 - clk[1][1]

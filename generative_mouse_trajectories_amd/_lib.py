@@ -10,7 +10,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libgmt_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 ERRORS = {-1: 'bad argument (null pointer / shape / alignment)', -2: 'unsupported configuration',
@@ -72,6 +72,7 @@ _SIGS = {
     'gmt_lstm_layer_fwd': [c_p] * 10 + [c_i] * 5 + [c_f, ctypes.c_uint, c_p],
     'gmt_lstm_layer_bwd': [c_p] * 11 + [c_i] * 4 + [c_f, ctypes.c_uint, c_p],
     'gmt_lstm_layer_bwd2': [c_p] * 12 + [c_i] * 5 + [c_p],
+    'gmt_lstm_xproj': [c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p],
     'gmt_wgrad_workspace_floats': [c_i, c_i, c_ll, c_p, c_p],
     'gmt_wgrad': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_ll, c_f, ctypes.c_uint, c_p],
     'gmt_wgrad_noalloc_init': [],

@@ -19,7 +19,8 @@ namespace {
 
 template <int NW, bool RES, int IX>
 __global__ __launch_bounds__(NW * 64, 1)
-void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ w_ih_pk,
+void lstm_bwd2_kernel(const float* __restrict__ xhat /* IX = 0: [ndir][L][B][4H] = xhat W_ih^T, hoisted (gmt_lstm_xproj) */,
+                      const float* __restrict__ w_ih_pk,
                       const float* __restrict__ w_hh_pk, const int* __restrict__ lengths,
                       const float* __restrict__ gates, const float* __restrict__ c_all,
                       const float* __restrict__ dct_all, const float* __restrict__ dht_all,
@@ -29,13 +30,13 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
 {
     constexpr int H = NW * 32;
     constexpr int KS = H / 2;
-    constexpr int I = IX * H;
+    constexpr int I = IX * H;                          // IX = 0: the input contraction was hoisted out of the loop
     constexpr int NT = NW * 64;
     extern __shared__ float smem[];
     float* hT = smem;                                  // [2][H][LDA]  hhat state
     float* xT = smem + 2 * H * GMT_LDA;                // [2][I][LDA]
     // at H = 128 the last KL k-steps of W_hh live in LDS, not registers (as in lstm_fwd_kernel)
-    constexpr int KL = (RES && NW == 4) ? (IX == 1 ? 16 : 8) : 0;
+    constexpr int KL = (RES && NW == 4) ? (IX == 2 ? 8 : IX == 1 ? 16 : 24) : 0;
     constexpr int KR = KS - KL;
     float4* wl = reinterpret_cast<float4*>(smem + (2 * H + 2 * I) * GMT_LDA) + (size_t)(threadIdx.x >> 6) * (KL / 4) * 4 * 64;
     __shared__ int s_len[GMT_TM];
@@ -61,7 +62,7 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
     const int tmax = s_maxlen;
 
     const float4* whh = reinterpret_cast<const float4*>(w_hh_pk) + ((size_t)dir * NW + wave) * (H / 8) * 4 * 64;
-    const float4* wih = reinterpret_cast<const float4*>(w_ih_pk) + ((size_t)dir * NW + wave) * (I / 8) * 4 * 64;
+    const float4* wih = IX > 0 ? reinterpret_cast<const float4*>(w_ih_pk) + ((size_t)dir * NW + wave) * (I / 8) * 4 * 64 : nullptr;
     float wr[4][RES ? KR : 1];
     if constexpr (RES) {
         gmt_load_resident<4, KR>(wr, whh, lane);
@@ -73,21 +74,25 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { chat[r] = 0.f; gc_pend[r] = 0.f; }
 
-    constexpr int XQ = I / 4;
-    constexpr int XS = (GMT_TM * XQ) / NT;
+    constexpr int XQ = IX > 0 ? I / 4 : 1;
+    constexpr int XS = IX > 0 ? (GMT_TM * XQ) / NT : 1;
     float4 xs[XS];
     auto x_load = [&](int t) {
-        const float4* src = reinterpret_cast<const float4*>(xhat + ((size_t)t * B + row0) * I);
+        if constexpr (IX > 0) {
+            const float4* src = reinterpret_cast<const float4*>(xhat + ((size_t)t * B + row0) * I);
 #pragma unroll
-        for (int j = 0; j < XS; ++j) xs[j] = src[tid + j * NT];
+            for (int j = 0; j < XS; ++j) xs[j] = src[tid + j * NT];
+        }
     };
     auto x_store = [&](int buf) {
+        if constexpr (IX > 0) {
 #pragma unroll
-        for (int j = 0; j < XS; ++j) {
-            const int it = tid + j * NT;
-            const int rr = it / XQ, c4 = it % XQ;
-            float* d = xT + ((size_t)buf * I + 4 * c4) * GMT_LDA + rr;
-            d[0] = xs[j].x; d[GMT_LDA] = xs[j].y; d[2 * GMT_LDA] = xs[j].z; d[3 * GMT_LDA] = xs[j].w;
+            for (int j = 0; j < XS; ++j) {
+                const int it = tid + j * NT;
+                const int rr = it / XQ, c4 = it % XQ;
+                float* d = xT + ((size_t)buf * I + 4 * c4) * GMT_LDA + rr;
+                d[0] = xs[j].x; d[GMT_LDA] = xs[j].y; d[2 * GMT_LDA] = xs[j].z; d[3 * GMT_LDA] = xs[j].w;
+            }
         }
     };
 
@@ -107,13 +112,14 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-        gmt_mma_stream<4>(acc, xT + (size_t)cur * I * GMT_LDA, wih, I, lane);
+        if constexpr (IX > 0) gmt_mma_stream<4>(acc, xT + (size_t)cur * I * GMT_LDA, wih, I, lane);
         if constexpr (RES) gmt_mma_resident<4, KS, KR>(acc, hT + (size_t)cur * H * GMT_LDA, wr, lane, wl);
         else gmt_mma_stream<4>(acc, hT + (size_t)cur * H * GMT_LDA, whh, H, lane);
 
         const float* ho = hT + (size_t)cur * H * GMT_LDA + col * GMT_LDA + 4 * hi;
         float* hn = hT + (size_t)(cur ^ 1) * H * GMT_LDA + col * GMT_LDA + 4 * hi;
         const float* gp = gates + rs * (4 * H) + 4 * col;
+        const float* pre_p = xhat + rs * (4 * H) + 4 * col;       // IX = 0 only
         const float* cn_p = c_all + rs * H + col;
         const float* cp_p = c_all + rsp * H + col;
         const float* dct_p = dct_all + rs * H + col;
@@ -129,12 +135,13 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
         // registers for one step (gc_pend) and stored then, instead of a read-modify-write.
 #pragma unroll
         for (int half = 0; half < 16 / RB; ++half) {
-            float4 q4[RB];
+            float4 q4[RB], p4[IX == 0 ? RB : 1];
             float v_cn[RB], v_cp[RB], v_dct[RB], v_dht[RB];
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
                 const int r = half * RB + j, mr = (r & 3) + 8 * (r >> 2);
                 q4[j] = gmt_ld4(gp + (size_t)mr * (4 * H));
+                if constexpr (IX == 0) p4[j] = gmt_ld4(pre_p + (size_t)mr * (4 * H));
                 v_cn[j] = cn_p[(size_t)mr * H];
                 v_cp[j] = cp_p[(size_t)mr * H];
                 v_dct[j] = dct_p[(size_t)mr * H];
@@ -154,7 +161,8 @@ void lstm_bwd2_kernel(const float* __restrict__ xhat, const float* __restrict__ 
                 const float omt = 1.f - tc * tc;
                 // intermediates of the first backward sweep
                 const float di = dct * gg, dg = dct * ig, df = dct * cp, dov = dht * tc;
-                const float a_i = acc[0][r], a_f = acc[1][r], a_g = acc[2][r], a_o = acc[3][r];
+                float a_i = acc[0][r], a_f = acc[1][r], a_g = acc[2][r], a_o = acc[3][r];
+                if constexpr (IX == 0) { a_i += p4[j].x; a_f += p4[j].y; a_g += p4[j].z; a_o += p4[j].w; }
                 const float adi = a_i * ig * (1.f - ig);
                 const float adf = a_f * fg * (1.f - fg);
                 const float adg = a_g * (1.f - gg * gg);
@@ -221,7 +229,7 @@ int launch_bwd2(const float* xhat, const float* w_ih_pk, const float* w_hh_pk, c
 #define GMT_GO(IXV)                                                                                               \
     {                                                                                                             \
         const size_t lds = (size_t)(2 * H + 2 * IXV * H) * GMT_LDA * sizeof(float)                                \
-                           + ((RES && NW == 4) ? (size_t)NW * (IXV == 1 ? 16 : 8) * 4 * 64 * sizeof(float) : 0);  \
+                           + ((RES && NW == 4) ? (size_t)NW * (IXV == 2 ? 8 : IXV == 1 ? 16 : 24) * 4 * 64 * sizeof(float) : 0); \
         if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;                                                   \
         auto k = lstm_bwd2_kernel<NW, RES, IXV>;                                                                  \
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
@@ -229,7 +237,8 @@ int launch_bwd2(const float* xhat, const float* w_ih_pk, const float* w_hh_pk, c
         hipLaunchKernelGGL(k, grid, block, lds, stream, xhat, w_ih_pk, w_hh_pk, lengths, gates, c_all, dct_all,   \
                            dht_all, hhat_all, hhat_final, g_gates, g_c, L, B, ndir, n_tiles);                     \
     }
-    if (I == H) GMT_GO(1)
+    if (!w_ih_pk) GMT_GO(0)
+    else if (I == H) GMT_GO(1)
     else if (I == 2 * H) GMT_GO(2)
     else return GMT_ERR_UNSUPPORTED;
 #undef GMT_GO
@@ -244,7 +253,7 @@ extern "C" int gmt_lstm_layer_bwd2(const float* xhat, const float* w_ih_pk, cons
                                    float* hhat_all, float* hhat_final, float* g_gates, float* g_c,
                                    int L, int B, int I, int H, int ndir, hipStream_t stream)
 {
-    GMT_CHECK_ARG(xhat && w_ih_pk && w_hh_pk && gates && c_all && dct_all && dht_all && g_gates && g_c);
+    GMT_CHECK_ARG(xhat && w_hh_pk && gates && c_all && dct_all && dht_all && g_gates && g_c);
     GMT_CHECK_ARG(L >= 1 && B >= GMT_TM && (B % GMT_TM) == 0 && (ndir == 1 || ndir == 2));
     switch (H) {
         case 32: return launch_bwd2<1>(xhat, w_ih_pk, w_hh_pk, lengths, gates, c_all, dct_all, dht_all, hhat_all,

@@ -69,8 +69,8 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
     const float x_keep_scale = 1.0f / (1.0f - x_drop_p);
     constexpr int NT = NW * 64;
     extern __shared__ float smem[];
-    // at H = 128 with the fused input contraction the last KL k-steps of W_hh live in LDS, not registers
-    constexpr int KL = (RES && NW == 4 && IX > 0) ? GMT_FWD_KL : 0;
+    // at H = 128 the last KL k-steps of W_hh live in LDS, not registers
+    constexpr int KL = (RES && NW == 4) ? GMT_FWD_KL : 0;   // (IX = 0: the prefetched pregates need the registers)
     constexpr int KR = KS - KL;
     float* hT = smem;                                  // [H][LDA]  h_{t-1}, transposed (MFMA A operand)
     float* xT = smem + H * GMT_LDA;                    // [I][LDA]  x_t, transposed (IX > 0 only)
@@ -158,6 +158,17 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
     }
 
     const size_t lane_row = (size_t)row0 + 4 * hi;     // first row of this lane's accumulator rows
+    // IX = 0: the hoisted x W_ih^T + b of this lane's 16 (row, unit) pairs, one float4 (i,f,g,o) each; requested a
+    // whole step ahead (right after the previous step consumed its own), added to the recurrent part after the MFMAs
+    float4 pv[IX == 0 ? 16 : 1];
+    auto p_load = [&](int t) {
+        const float* pp = pregates + (((size_t)dir * L + t) * B + lane_row) * (4 * H) + 4 * col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pv[r] = gmt_ld4(pp + (size_t)((r & 3) + 8 * (r >> 2)) * (4 * H));
+    };
+    if constexpr (IX == 0) {
+        if (tmax > 0) p_load(dir ? tmax - 1 : 0);
+    }
     float* hs = hT + col * GMT_LDA + 4 * hi;           // this lane's 16 state slots (updated in place)
     GMT_PH_DECL;
     for (int step = 0; step < tmax; ++step) {
@@ -171,12 +182,10 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][r] = bz[g];
         } else {
-            const float* pp = pregates + rs * (4 * H) + 4 * col;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float4 v = gmt_ld4(pp + (size_t)((r & 3) + 8 * (r >> 2)) * (4 * H));
-                acc[0][r] = v.x; acc[1][r] = v.y; acc[2][r] = v.z; acc[3][r] = v.w;
-            }
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
         }
         if constexpr (RES) gmt_mma_resident<4, KS, KR>(acc, hT, wr, lane, wl);
         else gmt_mma_stream<4>(acc, hT, whh, H, lane);
@@ -192,6 +201,13 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
             const int tn = (step + 1 < tmax) ? (dir ? t - 1 : t + 1) : t;
             x_load(tn);
             GMT_PH(0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[0][r] += pv[r].x; acc[1][r] += pv[r].y; acc[2][r] += pv[r].z; acc[3][r] += pv[r].w;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            p_load((step + 1 < tmax) ? (dir ? t - 1 : t + 1) : t);     // unconditional, like x_load
         }
 
         float* gp = gates ? gates + rs * (4 * H) + 4 * col : nullptr;
@@ -488,7 +504,7 @@ int launch_fwd(const float* x, const float* pregates, const float* w_ih_pk, cons
 #define GMT_GO(IXV, LDSF)                                                                                         \
     {                                                                                                             \
         const size_t lds = (size_t)(LDSF) * GMT_LDA * sizeof(float)                                               \
-                           + ((RES && NW == 4 && IXV > 0) ? (size_t)NW * GMT_FWD_KL * 4 * 64 * sizeof(float) : 0); \
+                           + ((RES && NW == 4) ? (size_t)NW * GMT_FWD_KL * 4 * 64 * sizeof(float) : 0);             \
         if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;                                                   \
         auto k = full ? lstm_fwd_kernel<NW, RES, IXV, true> : lstm_fwd_kernel<NW, RES, IXV, false>;               \
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \

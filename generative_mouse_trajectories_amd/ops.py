@@ -2,9 +2,10 @@
 
 Every Function here is a thin host wrapper: it allocates the output / saved buffers with
 torch (PyTorch owns device memory and streams), calls the C ABI on the current stream and
-returns.  The large time-parallel contractions that are plain GEMMs (input projections,
-weight gradients over K = L*B) go to rocBLAS through torch.mm; everything recurrent,
-element-wise or reducing is hand-written HIP.  GPU only - there is no CPU path.
+returns.  Every contraction of a train step - recurrent, input-gradient (csrc/dx_gemm.hip), weight-gradient
+over K = L*B rows (csrc/wgrad.hip), hoisted input projection (csrc/xproj.hip) - is hand-written HIP, and so is
+everything element-wise or reducing on the hot path; torch.mm is the fallback for shapes outside the kernels'
+tables only.  GPU only - there is no CPU path.
 """
 from __future__ import annotations
 
@@ -384,6 +385,21 @@ def _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd, x_drop=(0.0, 0)):
     return grads
 
 
+# The gradient-penalty sub-batch is a quarter of the batch (RG.py:969-989): its persistent kernels occupy a quarter of
+# the CUs, so the time-parallel input contractions of that path are hoisted out of the time loops and run on the whole
+# machine (csrc/xproj.hip); the full-batch path keeps them fused (same MFMA work either way, one pass less over x).
+GP_HOIST_XPROJ = True
+
+
+def lstm_xproj(x2: torch.Tensor, w_ih_pk: torch.Tensor, bias: Optional[torch.Tensor], nd: int, H: int, label: str) -> torch.Tensor:
+    """x2 [R, I] -> [nd, R, 4H] = x W_ih^T (+ bias [nd, 4H]) in the gate buffers' unit-major column order."""
+    R, I = x2.shape
+    pre = torch.empty(nd, R, 4 * H, device=x2.device, dtype=torch.float32)
+    L_.call('gmt_lstm_xproj', L_.ptr(x2), L_.ptr(w_ih_pk), L_.ptr(bias), L_.ptr(pre), R, I, H, nd, L_.stream(),
+            label=label, flops=2.0 * nd * R * 4 * H * I)
+    return pre
+
+
 class LSTMLayerBwdGPFn(torch.autograd.Function):
     """The first backward sweep of a layer as a differentiable op (gradient penalty only):
     (dh_all, dh_final, gates, c_all, w_ih.., w_hh..) -> dx.  Its backward is the second-order
@@ -426,10 +442,18 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         g_c = torch.empty_like(c_all)
         w_ih_pk = derived('ih_pk', w_ih, lambda: pack_forward(w_ih, H, I))
         w_hh_pk = derived('hh_pk', w_hh, lambda: pack_forward(w_hh, H, H))
-        L_.call('gmt_lstm_layer_bwd2', L_.ptr(xhat), L_.ptr(w_ih_pk), L_.ptr(w_hh_pk), L_.ptr(lengths),
-                L_.ptr(gates), L_.ptr(c_all), L_.ptr(dct), L_.ptr(dht), L_.ptr(hhat_all), L_.ptr(hhat_final),
-                L_.ptr(g_gates), L_.ptr(g_c), L, B, I, H, nd, L_.stream(), label='lstm_bwd2',
-                flops=2.0 * nd * L * B * 4 * H * (I + H))
+        if GP_HOIST_XPROJ:
+            pre = lstm_xproj(xhat.view(L * B, I), w_ih_pk, None, nd, H, f'xproj_gp_I{I // H}')
+            L_.call('gmt_lstm_layer_bwd2', L_.ptr(pre), None, L_.ptr(w_hh_pk), L_.ptr(lengths),
+                    L_.ptr(gates), L_.ptr(c_all), L_.ptr(dct), L_.ptr(dht), L_.ptr(hhat_all), L_.ptr(hhat_final),
+                    L_.ptr(g_gates), L_.ptr(g_c), L, B, I, H, nd, L_.stream(), label='lstm_bwd2_h',
+                    flops=2.0 * nd * L * B * 4 * H * H)
+            del pre
+        else:
+            L_.call('gmt_lstm_layer_bwd2', L_.ptr(xhat), L_.ptr(w_ih_pk), L_.ptr(w_hh_pk), L_.ptr(lengths),
+                    L_.ptr(gates), L_.ptr(c_all), L_.ptr(dct), L_.ptr(dht), L_.ptr(hhat_all), L_.ptr(hhat_final),
+                    L_.ptr(g_gates), L_.ptr(g_c), L, B, I, H, nd, L_.stream(), label='lstm_bwd2',
+                    flops=2.0 * nd * L * B * 4 * H * (I + H))
         xh2 = xhat.view(L * B, I)
         g_wih, g_whh = [], []
         for d in range(nd):
@@ -466,9 +490,18 @@ class LSTMLayerGPFn(torch.autograd.Function):
         h_final = torch.empty(B, nd * H, device=dev, dtype=torch.float32)
         w_ih_pk = derived('ih_pk', w_ih, lambda: pack_forward(w_ih, H, I))
         w_hh_pk = derived('hh_pk', w_hh, lambda: pack_forward(w_hh, H, H))
-        L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(w_ih_pk), L_.ptr(w_hh_pk),
-                L_.ptr(bias), L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
-                L, B, I, H, nd, 0.0, 0, L_.stream(), label=f'lstm_fwd_gp_I{I // H}', flops=2.0 * nd * L * B * 4 * H * (I + H))
+        if GP_HOIST_XPROJ:
+            # x W_ih^T + b straight into the gate buffer (a full-machine launch); the persistent kernel reads its
+            # step's slice from there a step ahead and overwrites it with the activated gates
+            L_.call('gmt_lstm_xproj', L_.ptr(x), L_.ptr(w_ih_pk), L_.ptr(bias), L_.ptr(gates), L * B, I, H, nd, L_.stream(),
+                    label=f'xproj_gp_I{I // H}', flops=2.0 * nd * L * B * 4 * H * I)
+            L_.call('gmt_lstm_layer_fwd', None, L_.ptr(gates), None, L_.ptr(w_hh_pk), None, L_.ptr(lengths),
+                    L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final), L, B, I, H, nd, 0.0, 0, L_.stream(),
+                    label='lstm_fwd_gp_h', flops=2.0 * nd * L * B * 4 * H * H)
+        else:
+            L_.call('gmt_lstm_layer_fwd', L_.ptr(x), None, L_.ptr(w_ih_pk), L_.ptr(w_hh_pk),
+                    L_.ptr(bias), L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
+                    L, B, I, H, nd, 0.0, 0, L_.stream(), label=f'lstm_fwd_gp_I{I // H}', flops=2.0 * nd * L * B * 4 * H * (I + H))
         ctx.save_for_backward(x, lengths, gates, c_all, h_all, *weights)
         ctx.dims = (L, B, I, H, nd)
         ctx.set_materialize_grads(False)
@@ -760,6 +793,9 @@ def gen_backward_packs(w_hh0, w_ih1, w_hh1, w1):
     return derived('gen_bwd_pk', [w_hh0, w_ih1, w_hh1, w1], build)
 
 
+AFTER_GEN_BWD_LAUNCH: list = []       # at most one callable(event recorded just before the BPTT launch); one-shot
+
+
 class GenRolloutFn(torch.autograd.Function):
     """Inputs (all fp32, cuda):
       g0 [B,4H] (unit-major columns 4*unit + gate), w_u [4H,7], w_hh0 [4H,H], w_ih1 [4H,H], w_hh1 [4H,H], bias1 [4H],
@@ -855,8 +891,19 @@ class GenRolloutFn(torch.autograd.Function):
         a.d_ypre = d_ypre.data_ptr(); a.d_o = d_o.data_ptr(); a.d_in0 = d_in0.data_ptr()
         a.T, a.B, a.H = T, B, H
         a.dropout_p, a.seed = ctx.drop
+        hook = AFTER_GEN_BWD_LAUNCH[0] if AFTER_GEN_BWD_LAUNCH else None
+        before = None
+        if hook is not None:
+            before = torch.cuda.Event()
+            before.record()
         L_.call('gmt_gen_rollout_bwd', ctypes_byref(a), L_.stream(), label='gen_bwd',
                 flops=float(T) * B * (ctx.g_exec - 8 * H * 7))      # the data-gradient half of the backward (dW: gmt_wgrad)
+        if hook is not None:
+            # the BPTT kernel is B / 32 workgroups (half the CUs at B = 4096): whoever registered the hook may now
+            # enqueue independent work on ANOTHER stream that waits for `before` only (Trainer: the next D step's
+            # real-sample critic forward), so that it runs beside this launch instead of after it
+            del AFTER_GEN_BWD_LAUNCH[:]
+            hook(before)
         da0 = gates0.view(T * B, 4 * H)
         da1 = gates1.view(T * B, 4 * H)
         h0v, h1v = h0.view(T * B, H), h1.view(T * B, H)

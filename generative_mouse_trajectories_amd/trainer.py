@@ -316,8 +316,8 @@ class StepMetrics(dict):
     def keys(self): return dict.keys(self.wait())
     def __iter__(self): return dict.__iter__(self.wait())
     def __repr__(self): return dict.__repr__(self.wait())
-    def __eq__(self, other): return dict.__eq__(self.wait(), other)
-    def __ne__(self, other): return dict.__ne__(self.wait(), other)
+    def __eq__(self, other): return dict.__eq__(self.wait(), other.wait() if isinstance(other, StepMetrics) else other)
+    def __ne__(self, other): return dict.__ne__(self.wait(), other.wait() if isinstance(other, StepMetrics) else other)
     def copy(self): return dict(self.wait())
     def pop(self, *a): return dict.pop(self.wait(), *a)
     def setdefault(self, *a): return dict.setdefault(self.wait(), *a)
@@ -430,6 +430,13 @@ class Trainer:
         self._side = None
         self._spec = None
         self._g_version = 0
+        self._d_version = 0
+        self._spec_real = None         # see _launch_speculative_real_forward
+        self._main_stream = None
+        # two streams feed one set of parameters on purpose (the speculative launches above)
+        _quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if _quiet is not None:
+            _quiet(False)
         self.host_clock = None         # a list: the step functions append (tag, perf_counter()) when a step is fully enqueued
         # step functions return StepMetrics whose floats arrive asynchronously; the host may run at most this many
         # step-function calls ahead of the GPU (0: every step function blocks on its own read-back like the reference)
@@ -535,6 +542,30 @@ class Trainer:
         self._spec = {'batch': real_batch, 'g_version': self._g_version, 'tf_ratio': tf_ratio, 'tf_mask': tf_mask, 'out': out,
                       'z': z}
 
+    def _launch_speculative_real_forward(self, next_batch: Dict, before_bptt: 'torch.cuda.Event') -> None:
+        """Called from inside the generator step's backward pass right after the BPTT kernel was launched
+        (ops.AFTER_GEN_BWD_LAUNCH).  That kernel is B / 32 workgroups - half the CUs at B = 4096 - and nothing else of
+        the G step can run beside it.  The NEXT discriminator step's real-sample forward (RG.py:957) can: it depends
+        on D's weights and spectral-norm buffers as the G step's own critic call left them (D is not updated by a G
+        step) and on the next batch, nothing else.  It is enqueued here on the stream the BPTT kernel is NOT on,
+        ordered after `before_bptt`; train_discriminator_step(next_batch) picks it up.  Same arithmetic, same order of
+        power iterations on u / v as the reference (G step's critic call, then the D step's real call)."""
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device, priority=-1)
+        other = self._main_stream if cur == self._side else self._side
+        other.wait_event(before_bptt)
+        D = self.discriminator
+        with torch.enable_grad(), torch.cuda.stream(other):
+            starts, ends, sequences, lengths = self._to_dev(next_batch)
+            batch_size = sequences.shape[0]
+            Bp = ops.pad_rows(batch_size, ops.row_tile(self.config))
+            real_pos, real_dts = ops.traj_from_seq(sequences.float(), starts, False, batch_size, Bp)
+            lens_p1 = self._critic_inputs(lengths, Bp)
+            real_score = D.forward_tm(real_pos, real_dts, lens_p1)[:batch_size]
+        self._spec_real = {'batch': next_batch, 'd_version': self._d_version, 'training': D.training, 'stream': other,
+                           'real_pos': real_pos, 'real_dts': real_dts, 'lens_p1': lens_p1, 'real_score': real_score}
+
     def _critic_inputs(self, lengths: torch.Tensor, Bp: int) -> torch.Tensor:
         """lengths + 1 (positions incl. the start point, RG.py:957 / 960 / 1064) as the kernels' int32 [Bp]
         (clamped to >= 1 like RG.py:766; padding rows have length 1)."""
@@ -548,8 +579,21 @@ class Trainer:
         batch_size, T = sequences.shape[0], sequences.shape[1]
         Bp = ops.pad_rows(batch_size, ops.row_tile(self.config))
         G, D = self.generator, self.discriminator
-        # real_trajectories / real_dts_padded of RG.py:931-934, straight into the kernels' time-major padded layout
-        real_pos, real_dts = ops.traj_from_seq(sequences.float(), starts, False, batch_size, Bp)
+        spec_r, self._spec_real = self._spec_real, None
+        if not (spec_r is not None and spec_r['batch'] is real_batch and spec_r['d_version'] == self._d_version
+                and spec_r['training'] == D.training and spec_r['real_pos'].shape[1] == Bp):
+            spec_r = None
+        if spec_r is not None:
+            # this step's real-sample critic forward was launched beside the previous G step's BPTT kernel
+            main = torch.cuda.current_stream()
+            if spec_r['stream'] != main:
+                main.wait_stream(spec_r['stream'])
+                for t_ in (spec_r['real_pos'], spec_r['real_dts'], spec_r['lens_p1'], spec_r['real_score']):
+                    t_.record_stream(main)
+            real_pos, real_dts = spec_r['real_pos'], spec_r['real_dts']
+        else:
+            # real_trajectories / real_dts_padded of RG.py:931-934, straight into the kernels' time-major padded layout
+            real_pos, real_dts = ops.traj_from_seq(sequences.float(), starts, False, batch_size, Bp)
         z = noise.get('z')
         z = torch.randn(batch_size, cfg.latent_dim, device=self.device) if z is None else z.to(self.device)
         if self.overlap_g_forward and self.device.type == 'cuda' and (self.d_step + 1) % max(1, cfg.n_critic) == 0:
@@ -558,7 +602,7 @@ class Trainer:
             fake_tm = G.forward_tm(starts, ends, z, sequences, [False] * T)              # (T,Bp,3), RG.py:938-944
             fake_pos, fake_dts = ops.traj_from_seq(fake_tm, starts, True, batch_size, Bp)     # RG.py:946-949
         lens_p1 = self._critic_inputs(lengths, Bp)
-        real_score = D.forward_tm(real_pos, real_dts, lens_p1)[:batch_size]
+        real_score = spec_r['real_score'] if spec_r is not None else D.forward_tm(real_pos, real_dts, lens_p1)[:batch_size]
         fake_score = D.forward_tm(fake_pos, fake_dts, lens_p1)[:batch_size]              # fake_lengths == lengths (RG.py:599-600)
         d_loss = fake_score.mean() - real_score.mean()
         gp = torch.zeros((), device=self.device)
@@ -582,13 +626,19 @@ class Trainer:
         total_loss = d_loss + cfg.gradient_penalty_weight * gp
         self._backward_and_sync(total_loss, self.d_flat, self._d_sync)
         self.d_optimizer.step()
+        self._d_version += 1
         if self.host_clock is not None:
             self.host_clock.append(('d_enqueued', __import__('time').perf_counter()))
         return self._metrics(('d_loss', 'd_gp', 'd_real_score', 'd_fake_score'),
                              [d_loss, gp, real_score.detach().mean(), fake_score.detach().mean()])
 
     # ---- generator step (RecurrentGAN.py:1031-1118) ---------------------------------
-    def train_generator_step(self, real_batch: Dict, noise: Optional[Dict] = None) -> Dict[str, float]:
+    def train_generator_step(self, real_batch: Dict, noise: Optional[Dict] = None,
+                             next_batch: Optional[Dict] = None) -> Dict[str, float]:
+        """next_batch (optional, not in the reference): the batch the NEXT train_discriminator_step will be given.
+        With it the real-sample critic forward of that step is launched beside this step's half-machine BPTT kernel
+        (_launch_speculative_real_forward).  Only pass it when that call is certain to follow: the forward advances
+        the spectral-norm power iteration like any critic call."""
         noise = noise or {}
         cfg = self.config
         self.g_optimizer.zero_grad()
@@ -641,7 +691,13 @@ class Trainer:
             direction_loss = nd[0] / nd[1]
             dir_for_grad = dir_num * (float(dist.get_world_size(self.process_group)) / nd[1])
         total_loss = g_loss + cfg.endpoint_loss_weight * endpoint_loss + cfg.direction_loss_weight * dir_for_grad
-        self._backward_and_sync(total_loss, self.g_flat, self._g_sync)
+        if next_batch is not None and self.discriminator.training:
+            self._main_stream = torch.cuda.current_stream()
+            ops.AFTER_GEN_BWD_LAUNCH[:] = [lambda ev, nb=next_batch: self._launch_speculative_real_forward(nb, ev)]
+        try:
+            self._backward_and_sync(total_loss, self.g_flat, self._g_sync)
+        finally:
+            del ops.AFTER_GEN_BWD_LAUNCH[:]
         self.g_optimizer.step()
         self._g_version += 1
         if self.host_clock is not None:
@@ -658,10 +714,14 @@ class Trainer:
                 'g_direction_loss', 'g_fake_score']
         epoch_metrics: Dict[str, List[float]] = {k: [] for k in keys}
         steps: List[Dict[str, float]] = []
-        for batch in dataloader:
+        it = iter(dataloader)
+        batch = next(it, None)
+        while batch is not None:
+            nxt = next(it, None)                       # one batch of look-ahead: the G step starts the next D step's real forward
             for _ in range(self.config.n_critic):
                 steps.append(self.train_discriminator_step(batch))
-            steps.append(self.train_generator_step(batch))
+            steps.append(self.train_generator_step(batch, next_batch=nxt if self.overlap_g_forward else None))
+            batch = nxt
         for m in steps:                                # read after the loop: the step functions never wait on the GPU
             for k, v in m.items():
                 if k in epoch_metrics:
@@ -718,6 +778,8 @@ class Trainer:
         self._g_version += 1
         self._spec = None
         self.discriminator.load_state_dict(checkpoint['discriminator_state_dict'])
+        self._d_version += 1
+        self._spec_real = None
         self.g_optimizer.load_state_dict(checkpoint['g_optimizer_state_dict'])
         self.d_optimizer.load_state_dict(checkpoint['d_optimizer_state_dict'])
         self.best_loss = checkpoint.get('best_loss', float('inf'))

@@ -39,7 +39,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define GMT_ERR_WORKSPACE (-4)    /* caller's workspace is too small                     */
 
 /* ABI version of this header; gmt_version() of the loaded library must match. */
-#define GMT_ABI_VERSION 7
+#define GMT_ABI_VERSION 8
 int gmt_version(void);
 
 /* ---- kinematic features, "mode A" ---------------------------------------------------
@@ -200,6 +200,14 @@ int gmt_lstm_layer_fwd(const float* x, const float* pregates, const float* w_ih_
                        float* h_final, int L, int B, int I, int H, int ndir,
                        float x_dropout_p, unsigned x_dropout_seed, hipStream_t stream);
 
+/* gmt_lstm_xproj: the time-parallel half of the same layer, x W_ih^T + (b_ih + b_hh), for all R = L*B row-steps and
+ * both directions in one launch (RG.py:772: what nn.LSTM computes per step): x [R][I], w_ih_pk as above,
+ * bias [ndir][4H] or NULL -> pregates [ndir][R][4H] (unit-major columns), to be passed to gmt_lstm_layer_fwd as
+ * `pregates` (x = NULL).  The gradient-penalty sub-batch (a quarter of the batch: a quarter of the CUs in the
+ * persistent kernels) runs this part on the whole machine.  I in {H, 2H}, R % 32 == 0. */
+int gmt_lstm_xproj(const float* x, const float* w_ih_pk, const float* bias, float* pregates,
+                   long long R, int I, int H, int ndir, hipStream_t stream);
+
 /* gmt_lstm_layer_bwd: reverse sweep of the same layer (what autograd does for RG.py:1021,
  * 1109).  In: gates / c_all saved by the forward, dh_all [L][B][ndir*H] and / or dh_final
  * [B][ndir*H] (either may be NULL), w_hh_pkT [ndir] packed (K = 4H, n_gates 1,
@@ -224,7 +232,9 @@ int gmt_lstm_layer_bwd(float* gates, const float* c_all, const float* w_hh_pkT, 
  * and the dct / dht buffers of the first backward sweep.  Out: hhat_all [L][B][ndir*H]
  * (adjoint of dh_all; may be NULL), hhat_final [B][ndir*H] (adjoint of dh_final; may be
  * NULL), g_gates [ndir][L][B][4H] and g_c [ndir][L][B][H] (adjoints of the saved
- * activations, to be passed to gmt_lstm_layer_bwd as dgates_extra / dc_extra). */
+ * activations, to be passed to gmt_lstm_layer_bwd as dgates_extra / dc_extra).
+ * Hoisted form: w_ih_pk == NULL and xhat = [ndir][L][B][4H] = xhat W_ih^T computed for all timesteps by
+ * gmt_lstm_xproj (bias NULL); I is ignored. */
 int gmt_lstm_layer_bwd2(const float* xhat, const float* w_ih_pk, const float* w_hh_pk, const int* lengths,
                         const float* gates, const float* c_all, const float* dct_all, const float* dht_all,
                         float* hhat_all, float* hhat_final, float* g_gates, float* g_c,

@@ -186,3 +186,33 @@ def test_teacher_forcing_schedule():
     assert O.teacher_forcing_ratio(0, oc) == 1.0
     assert abs(O.teacher_forcing_ratio(50, oc) - 0.5) < 1e-12
     assert O.teacher_forcing_ratio(100, oc) == 0.0
+
+
+def test_step_metrics_resolve_on_every_kind_of_read():
+    """trainer.StepMetrics: the dict a step function returns fills itself in at the first read of a value, whatever
+    the way of reading; keys / len / `in` never wait."""
+    import json
+    import pickle
+    from generative_mouse_trajectories_amd.trainer import StepMetrics
+
+    class Ev:
+        def __init__(self): self.n = 0
+        def synchronize(self): self.n += 1
+        def query(self): return True
+
+    def make():
+        ev = Ev()
+        return StepMetrics(('a', 'b'), torch.tensor([1.5, 2.5]), ev, {'c': 3.0}), ev
+
+    want = {'a': 1.5, 'b': 2.5, 'c': 3.0}
+    m, ev = make()
+    assert len(m) == 3 and 'a' in m and ev.n == 0
+    assert m['a'] == 1.5 and ev.n == 1 and m['b'] == 2.5 and ev.n == 1
+    for read in (lambda m: dict(m), lambda m: {**m}, lambda m: json.loads(json.dumps(m)), lambda m: dict(m.items()),
+                 lambda m: m.copy(), lambda m: {k: m[k] for k in m}, lambda m: pickle.loads(pickle.dumps(m)),
+                 lambda m: dict(zip(m.keys(), m.values())), lambda m: {k: m.get(k) for k in ('a', 'b', 'c')},
+                 lambda m: eval(repr(m))):
+        m, ev = make()
+        assert read(m) == want and ev.n == 1
+    m1, _ = make(); m2, _ = make()
+    assert m1 == m2 and (m1, m2) == (want, want) and not (m1 != m2)

@@ -291,19 +291,34 @@ def test_overlapped_generator_forward_is_the_same_step():
     batch = {'starts': starts.to(dev), 'ends': (starts + deltas.sum(1)).to(dev),
              'sequences': torch.cat([deltas, torch.rand(B, T, 1, generator=g) * 0.02 + 0.004], -1).to(dev),
              'lengths': torch.randint(3, T + 1, (B,), generator=g).sort(descending=True).values.to(dev)}
-    for it in range(2):
+    # tr1 also gets the `next_batch` hint: the next D step's real-sample critic forward is launched from inside the
+    # G step's backward, beside the BPTT kernel (Trainer._launch_speculative_real_forward) - same arithmetic, same
+    # order of spectral-norm power iterations, so the steps stay the same to the bit
+    for it in range(3):
         nd = {'z': torch.randn(B, cfg.latent_dim, generator=g), 'gp_idx': torch.randperm(B, generator=g),
               'alpha': torch.rand(-(-B // 4), generator=g)}
+        assert (tr1._spec_real is not None) == (it > 0)
         r1 = tr1.train_discriminator_step(batch, dict(nd))
+        assert tr1._spec_real is None
         spec = tr1._spec
         assert spec is not None
         zs, mask = spec['z'].clone(), list(spec['tf_mask'])
         r2 = tr2.train_discriminator_step(batch, dict(nd))
         for k in r1:
             assert abs(r1[k] - r2[k]) <= 1e-6 * max(1.0, abs(r2[k])), (k, r1[k], r2[k])
-        g1 = tr1.train_generator_step(batch)
+        g1 = tr1.train_generator_step(batch, next_batch=batch if it < 2 else None)   # (the last one starts nothing)
         assert tr1._spec is None
         g2 = tr2.train_generator_step(batch, {'z': zs, 'tf_mask': mask})
         for k in g1:
             assert abs(g1[k] - g2[k]) <= 1e-6 * max(1.0, abs(g2[k])), (k, g1[k], g2[k])
-    H.assert_close(tr1.g_flat.flat, tr2.g_flat.flat, 1e-6, 'G parameters after two overlapped iterations')
+    torch.cuda.synchronize()
+    H.assert_close(tr1.g_flat.flat, tr2.g_flat.flat, 1e-6, 'G parameters after three overlapped iterations')
+    H.assert_close(tr1.d_flat.flat, tr2.d_flat.flat, 1e-6, 'D parameters after three overlapped iterations')
+    for b1, b2 in zip(tr1.discriminator.buffers(), tr2.discriminator.buffers()):
+        assert torch.equal(b1, b2)                   # spectral-norm u / v advanced in the same order
+    # a hint that is not followed up (another batch object) is dropped, not used
+    other = dict(batch)
+    tr1.train_generator_step(batch, next_batch=batch)
+    assert tr1._spec_real is not None
+    tr1.train_discriminator_step(other)
+    assert tr1._spec_real is None

@@ -18,10 +18,10 @@ timeout -k 10 300 python3 tools/bench_kernels.py > $out/${tag}_per_kernel_roofli
 echo "per-kernel done"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d /tmp/${tag}_pmc_$c -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $out/${tag}_pmc_$c.err
-  python3 scratch/pmc_table.py /tmp/${tag}_pmc_$c > $out/${tag}_pmc_bench_$c.txt
+  python3 tools/pmc_table.py /tmp/${tag}_pmc_$c > $out/${tag}_pmc_bench_$c.txt
   echo "pmc $c (bench) done"
   timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d /tmp/${tag}_pmck_$c -- python3 tools/bench_kernels.py > /dev/null 2> $out/${tag}_pmck_$c.err
-  python3 scratch/pmc_table.py /tmp/${tag}_pmck_$c > $out/${tag}_pmc_kernels_$c.txt
+  python3 tools/pmc_table.py /tmp/${tag}_pmck_$c > $out/${tag}_pmc_kernels_$c.txt
   echo "pmc $c (kernels) done"
 done
 # config 3 (bf16, H = 512): bench line + kernel-trace summary + the forward step's fabric traffic
