@@ -461,7 +461,7 @@ extern "C" int gmt_bf16_gen_rollout_fwd(const gmt_bf16_gen_args* a, hipStream_t 
     GMT_CHECK_ARG(a && a->cond_pre && a->w0 && a->w1 && a->bias1 && a->wh1 && a->bh1 && a->wh2 && a->bh2 && a->ends && a->out_seq);
     GMT_CHECK_ARG(a->x0 && a->x1 && a->c0 && a->c1 && a->pos && a->T >= 1);
     GMT_CHECK_ARG(a->H == 512 && a->B > 0 && a->B % 256 == 0 && (!a->tf_mask || a->target));
-    GMT_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f && (long long)a->T * a->B * a->H < 0xffffffffLL);
+    GMT_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f && (a->dropout_p == 0.f || (long long)a->T * a->B * a->H < 0xffffffffLL));
     const bool train = a->gates0 != nullptr;        // training: every step keeps its state (x0 / x1 / c0 / c1 have T+1 slots)
     GMT_CHECK_ARG(!train || (a->gates1 && a->y_all && a->oraw_all));
     const int H = a->H, B = a->B, K0 = H + 64, K1 = 2 * H;

@@ -510,7 +510,7 @@ extern "C" int gmt_bf16_lstm_layer_fwd(void* gates, float* c_all, void* h_all, v
                                        unsigned int drop_seed, hipStream_t stream)
 {
     GMT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (h_drop == nullptr) == (drop_p == 0.f));
-    GMT_CHECK_ARG((long long)L * B * ndir * H < 0xffffffffLL);       // the mask's element counter is 32 bits
+    GMT_CHECK_ARG(drop_p == 0.f || (long long)L * B * ndir * H < 0xffffffffLL);   // the mask's element counter is 32 bits (no mask, no bound)
     GMT_CHECK_ARG(gates && c_all && h_all && w_hh && L >= 1 && (ndir == 1 || ndir == 2));
     GMT_CHECK_ARG(B > 0 && B % 256 == 0 && H > 0 && (4 * H) % TP == 0 && H % BK == 0 && (!ragged || lengths));
     const int n_mt = B / FWD_TQ, n_pt = 4 * H / TP;

@@ -61,18 +61,28 @@ int run_row_groups(int ng, int L, hipStream_t stream, F launch)
 {
     side_streams* ss = ng > 1 ? side_streams_of_device(ng - 1) : nullptr;
     if (ng > 1 && !ss) return GMT_ERR_HIP;
+    int rc = GMT_OK, forked = 0;
     if (ng > 1) {
-        if (hipEventRecord(ss->fork, stream) != hipSuccess) return GMT_ERR_HIP;
-        for (int g = 1; g < ng; ++g)
-            if (hipStreamWaitEvent(ss->s[g - 1], ss->fork, 0) != hipSuccess) return GMT_ERR_HIP;
+        if (hipEventRecord(ss->fork, stream) != hipSuccess) return GMT_ERR_HIP;      // nothing forked yet
+        for (int g = 1; g < ng && rc == GMT_OK; ++g) {
+            if (hipStreamWaitEvent(ss->s[g - 1], ss->fork, 0) != hipSuccess) rc = GMT_ERR_HIP;
+            else forked = g;
+        }
     }
-    for (int step = 0; step < L; ++step)
+    for (int step = 0; step < L && rc == GMT_OK; ++step) {
         for (int g = 0; g < ng; ++g) launch(g, step, g == 0 ? stream : ss->s[g - 1]);
-    for (int g = 1; g < ng; ++g) {
-        if (hipEventRecord(ss->join[g - 1], ss->s[g - 1]) != hipSuccess) return GMT_ERR_HIP;
-        if (hipStreamWaitEvent(stream, ss->join[g - 1], 0) != hipSuccess) return GMT_ERR_HIP;
+        if (hipGetLastError() != hipSuccess) rc = GMT_ERR_HIP;                       // stop issuing, still join below
     }
-    return GMT_OK;
+    // join whatever was forked, also on failure: the caller's stream must stay ordered after side-stream work on
+    // buffers the caller will free or reuse as soon as this call returns
+    for (int g = 1; g <= forked; ++g) {
+        if (hipEventRecord(ss->join[g - 1], ss->s[g - 1]) != hipSuccess ||
+            hipStreamWaitEvent(stream, ss->join[g - 1], 0) != hipSuccess) {
+            rc = GMT_ERR_HIP;
+            (void)hipStreamSynchronize(ss->s[g - 1]);                                    // last resort: order by waiting here
+        }
+    }
+    return rc;
 }
 
 }  // namespace gmt_bf16

@@ -128,6 +128,11 @@ class Generator(nn.Module):
         """Builds the cached fragment-major copies of the rollout's weights on the CURRENT stream (Trainer calls
         this before it launches a rollout on a second stream, so that both streams find them complete)."""
         lp = self.lstm
+        if self.bf16:
+            # H = 512: the bf16 / slab-ordered copies the no-grad rollout reads (the fp32 packs are never used there)
+            ops_bf16.gen_weights(lp.weight_ih_l0, lp.weight_hh_l0, lp.bias_ih_l0, lp.bias_hh_l0, lp.weight_ih_l1,
+                                 lp.weight_hh_l1, lp.bias_ih_l1, lp.bias_hh_l1, self.output_layer[0].weight)
+            return
         ops.gen_forward_packs(lp.weight_hh_l0, lp.weight_ih_l1, lp.weight_hh_l1, self.output_layer[0].weight)
 
     def _rollout(self, start, end, z, target_tm: Optional[torch.Tensor], tf_mask: Optional[torch.Tensor], T: int,
@@ -140,7 +145,9 @@ class Generator(nn.Module):
         B = start.shape[0]
         if self.bf16:
             return self._rollout_bf16(start, end, z, target_tm, tf_mask, T, stop_distance, padded, dropout_seed)
-        Bp = ops.pad_rows(B)
+        # (with a bf16 critic beside this fp32 rollout - compute_dtype 'bf16', H <= 256 here - the batch is padded to the
+        # critic's 256-row tile, so that the step functions' time-major buffers all have one row count)
+        Bp = ops.pad_rows(B, ops.row_tile(self.config))
         cond = self._compute_condition(start, end, z)
         lp = self.lstm
         w_ih0 = lp.weight_ih_l0

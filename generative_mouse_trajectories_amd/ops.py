@@ -108,7 +108,11 @@ def derived(kind: str, tensors, build):
     for the very same tensor objects (weak references: a new tensor that happens to get a dead one's address or
     id never matches), at the same autograd version (in-place torch updates bump it) and the same weights epoch
     (the fused Adam kernel and the load paths, which write behind autograd's back, call weights_changed()).
-    Never pass temporaries (e.g. spectrally normalised weights, which are new tensors every call)."""
+    Never pass temporaries (e.g. spectrally normalised weights, which are new tensors every call).
+    No stream is recorded with an entry: build() runs on the caller's current stream and later hits on ANOTHER stream
+    are only ordered after it if that stream was made to wait for the building one - so whoever uses a second stream
+    builds what that stream will read on the main stream first (Generator.prepack, called by the Trainer before it
+    forks) and forks afterwards."""
     import weakref
     key = (kind,) + tuple(id(t) for t in tensors)
     hit = _DERIVED.get(key)

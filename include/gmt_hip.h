@@ -15,7 +15,9 @@
  *   - work is enqueued on `stream` (a hipStream_t); calls are asynchronous;
  *   - return value: 0 (GMT_OK) or a negative GMT_ERR_* code; the host turns it into an
  *     exception;
- *   - no global mutable state; re-entrant (the autograd engine calls from its own thread);
+ *   - re-entrant (the autograd engine calls from its own thread); no global mutable state with two exceptions, both
+ *     per device and documented at their entry points: the bf16 row-group side stream + events (gmt_bf16_set_row_groups)
+ *     and the static scratch array of gmt_wgrad_noalloc;
  *   - tensors are fp32 and TIME-MAJOR unless said otherwise: [L][B][...] so that one
  *     timestep of all trajectories is contiguous.
  */

@@ -560,6 +560,55 @@ def test_bf16_train_steps_vs_fp64_oracle(ragged):
             assert abs(got[k] - v) <= bar * abs(v) + 5e-3, (k, got[k], v)
 
 
+def test_bf16_critic_with_fp32_generator_train_steps_vs_fp64_oracle():
+    """compute_dtype = 'bf16' with a critic of H = 256 (bf16 kernels, 256-row tiles) and a generator of H = 128 (<= 256: the fp32
+    rollout kernels, 32-row tiles): the step functions' time-major buffers must agree on one padded row count (round-2 advisor
+    finding: fake_tm came back with 32 rows against Bp = 256).  One D step with the penalty and one G step on 40 ragged
+    trajectories vs the fp64 oracle, at the bars of test_bf16_train_steps_vs_fp64_oracle."""
+    import generative_mouse_trajectories_amd as gmt
+    over = dict(latent_dim=16, generator_hidden_dim=128, discriminator_hidden_dim=256)
+    cfg = gmt.Config()
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    cfg.lstm_dropout = cfg.head_dropout = 0.0
+    cfg.compute_dtype = 'bf16'
+    oc = O.OracleConfig(**over)
+    pg = PG.make_generator_params(oc, 151)
+    pd, bd = PG.make_discriminator_params(oc, 152)
+    G, D = gmt.Generator(cfg), gmt.Discriminator(cfg)
+    assert D.bf16 and not G.bf16
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in pg.items()}, strict=True)
+    sd = {k: torch.from_numpy(v) for k, v in pd.items()}
+    sd.update({k: torch.from_numpy(v) for k, v in bd.items()})
+    D.load_state_dict(sd, strict=True)
+    tr = gmt.Trainer(G.to(DEV).train(), D.to(DEV).train(), cfg, torch.device(DEV), '/tmp/runs_gpu_bf16_mixed')
+    tr.epoch = 30
+    Bs, T = 40, 16
+    lengths = np.random.default_rng(156).integers(T // 2, T + 1, Bs).tolist()
+    b = H.batch_t(Bs, T, 153, lengths, torch.float32)
+    b['sequences'][:, :, 2] *= 50.0
+    g = torch.Generator().manual_seed(154)
+    nb = -(-Bs // 4)
+    noise = {'z': torch.randn(Bs, 16, generator=g), 'gp_idx': torch.randperm(Bs, generator=g), 'alpha': torch.rand(nb, generator=g)}
+    zg = torch.randn(Bs, 16, generator=g)
+    mask_tf = [bool(v) for v in (np.random.default_rng(155).random(T) < 0.7)]
+    m_d = tr.train_discriminator_step(b, dict(noise))
+    m_g = tr.train_generator_step(b, {'z': zg, 'tf_mask': mask_tf})
+    dt = torch.float64
+    Pg = {k: H.t(v, dt) for k, v in pg.items()}
+    Pd = {k: H.t(v, dt) for k, v in pd.items()}
+    Bd = {k: H.t(v, dt) for k, v in bd.items()}
+    bb = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in b.items()}
+    md, _, _ = O.discriminator_step(Pg, Pd, Bd, {}, bb, {'z': noise['z'].to(dt), 'gp_idx': noise['gp_idx'], 'alpha': noise['alpha'].to(dt)}, oc, 0)
+    mg, _, _ = O.generator_step(Pg, Pd, Bd, {}, bb, {'z': zg.to(dt)}, oc, mask_tf, tr.get_teacher_forcing_ratio())
+    print('mixed D step:', {k: (round(m_d[k], 5), round(float(v), 5)) for k, v in md.items()})
+    print('mixed G step:', {k: (round(m_g[k], 5), round(float(v), 5)) for k, v in mg.items()})
+    for got, ref in ((m_d, md), (m_g, mg)):
+        for k, v in ref.items():
+            bar = 1.5e-1 if k == 'd_gp' else 5e-2
+            assert abs(got[k] - v) <= bar * abs(v) + 5e-3, (k, got[k], v)
+
+
 def test_bf16_row_groups_do_not_change_results():
     """gmt_bf16_set_row_groups (include/gmt_hip.h): the critic's layer sweeps and the generator's rollout / BPTT run as one or
     two independent chains of step launches over disjoint row ranges (the second on the library's own stream).  Same
