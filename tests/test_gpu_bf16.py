@@ -248,18 +248,9 @@ def test_bf16_generator_rollout_vs_fp64_oracle():
             assert e <= 3e-2
 
 
-@pytest.mark.parametrize('head_shift,bar,p_drop', [(3.0, 6e-2, 0.0), (0.0, 2e-1, 0.0), (3.0, 6e-2, 0.1)])
-def test_bf16_generator_bptt_vs_fp64_oracle(head_shift, bar, p_drop):
-    """The training rollout + BPTT at H = 512 (three reverse launches per timestep, weight gradients as GEMMs over all T*B
-    row-steps) against the fp64 oracle: a fixed random linear functional of the outputs, free-running and with a mixed
-    teacher-forcing mask, every generator parameter.
-    head_shift = 3: output_layer.0.bias is raised so that every head unit sits on the linear side of its LeakyReLU - the
-    comparison then measures the sweep itself: 0.3-2.3 % of each gradient's max-norm (bar 6e-2, as for the critic).
-    head_shift = 0 (the generated parameters): an untrained head's pre-activations straddle zero, a bf16-sized forward error
-    flips the LeakyReLU branch of ~1 % of the units and every gradient inherits 2-10 % from that (bar 2e-1) - a property of
-    comparing a piecewise-linear net across precisions, also visible with T = 1.
-    p_drop = 0.1: nn.LSTM's inter-layer dropout (RG.py:451-457) as the counter-based mask inside the step kernels, forward and
-    BPTT; the oracle is handed the replayed mask."""
+def _bptt_case(Bs, T, seed, head_shift, p_drop, tf_masks, lengths=None):
+    """Training rollout + BPTT at H = 512 against the fp64 oracle: a fixed random linear functional of the outputs, every
+    generator parameter; returns per mask (output error, {parameter: relative max-norm error})."""
     import generative_mouse_trajectories_amd as gmt
     over = dict(latent_dim=16, generator_hidden_dim=512, discriminator_hidden_dim=32)
     cfg = gmt.Config()
@@ -267,19 +258,19 @@ def test_bf16_generator_bptt_vs_fp64_oracle(head_shift, bar, p_drop):
         setattr(cfg, k, v)
     cfg.compute_dtype = 'bf16'
     cfg.lstm_dropout = p_drop
-    Bs, T, seed = 200, 12, 121
     from generative_mouse_trajectories_amd import ops
     DSEED = 777
-    mask = ops.dropout_keep_mask(T, 256, 512, p_drop, DSEED)[:, :Bs] if p_drop > 0 else None
+    mask = ops.dropout_keep_mask(T, (Bs + 255) // 256 * 256, 512, p_drop, DSEED)[:, :Bs] if p_drop > 0 else None
     G = gmt.Generator(cfg)
     pg = PG.make_generator_params(O.OracleConfig(**over), seed)
     pg['output_layer.0.bias'] = pg['output_layer.0.bias'] + np.float32(head_shift)
     G.load_state_dict({k: torch.from_numpy(v) for k, v in pg.items()}, strict=True)
     G = G.to(DEV).train()
-    b = H.batch_t(Bs, T, seed + 1, [T] * Bs, torch.float32)
+    b = H.batch_t(Bs, T, seed + 1, lengths if lengths is not None else [T] * Bs, torch.float32)
     z = torch.randn(Bs, 16, generator=torch.Generator().manual_seed(seed + 2))
     R = torch.randn(Bs, T, 3, generator=torch.Generator().manual_seed(seed + 3))
-    for tf in ([False] * T, [True, False, False, True, False, True, True, False, False, False, True, False]):
+    res = []
+    for tf in tf_masks:
         G.zero_grad()
         out, _ = G(b['starts'].to(DEV), b['ends'].to(DEV), z.to(DEV), b['sequences'].to(DEV), tf_mask=tf, dropout_seed=DSEED)
         (out * R.to(DEV)).sum().backward()
@@ -294,8 +285,28 @@ def test_bf16_generator_bptt_vs_fp64_oracle(head_shift, bar, p_drop):
                 continue
             err[k] = H.relerr(prm.grad.cpu().reshape(gs[k].shape), gs[k])
         kmax = max(err, key=lambda k: err[k])
-        print(f'bf16 generator BPTT head_shift={head_shift} dropout={p_drop} tf={sum(tf)}/{T}: out {H.relerr(out.detach().cpu(), ref.detach()):.1e}, '
+        e_out = H.relerr(out.detach().cpu(), ref.detach())
+        print(f'bf16 generator BPTT B={Bs} T={T} head_shift={head_shift} dropout={p_drop} tf={sum(tf)}/{T}: out {e_out:.1e}, '
               f'worst gradient {err[kmax]:.1e} ({kmax})')
+        res.append((e_out, err))
+    return res
+
+
+@pytest.mark.parametrize('head_shift,bar,p_drop', [(3.0, 6e-2, 0.0), (0.0, 2e-1, 0.0), (3.0, 6e-2, 0.1)])
+def test_bf16_generator_bptt_vs_fp64_oracle(head_shift, bar, p_drop):
+    """The training rollout + BPTT at H = 512 (three reverse launches per timestep, weight gradients as GEMMs over all T*B
+    row-steps) against the fp64 oracle: a fixed random linear functional of the outputs, free-running and with a mixed
+    teacher-forcing mask, every generator parameter.
+    head_shift = 3: output_layer.0.bias is raised so that every head unit sits on the linear side of its LeakyReLU - the
+    comparison then measures the sweep itself: 0.3-2.3 % of each gradient's max-norm (bar 6e-2, as for the critic).
+    head_shift = 0 (the generated parameters): an untrained head's pre-activations straddle zero, a bf16-sized forward error
+    flips the LeakyReLU branch of ~1 % of the units and every gradient inherits 2-10 % from that (bar 2e-1) - a property of
+    comparing a piecewise-linear net across precisions, also visible with T = 1.
+    p_drop = 0.1: nn.LSTM's inter-layer dropout (RG.py:451-457) as the counter-based mask inside the step kernels, forward and
+    BPTT; the oracle is handed the replayed mask."""
+    T = 12
+    for _, err in _bptt_case(200, T, 121, head_shift, p_drop,
+                             ([False] * T, [True, False, False, True, False, True, True, False, False, False, True, False])):
         for k, v in err.items():
             assert v <= bar, (k, v)
 
@@ -508,14 +519,9 @@ def test_bf16_gradient_penalty_step_kernels():
     H.assert_close(planes(gc), gc32, 1e-2, 'adjoint of the saved cell states')
 
 
-@pytest.mark.parametrize('ragged', [False, True])
-def test_bf16_train_steps_vs_fp64_oracle(ragged):
-    """One full D step (with the gradient penalty on a quarter of the batch) and one G step of the Trainer with BOTH networks
-    at H = 512 on the bf16 kernels (BASELINE configs[2]'s width; T = 16, 256 full-length trajectories, time steps x 50 so the
-    features are O(1), dropout off for a deterministic comparison): every returned metric against the oracle's step functions
-    (RG.py:913-1118) in fp64.  Bars: 5e-2 on the Wasserstein / score / auxiliary-loss metrics (absolute floor 5e-3: the
-    untrained scores are ~1e-2), 1.5e-1 on the penalty (a squared gradient norm, which bf16 noise inflates - see
-    test_bf16_gradient_penalty_vs_fp64_oracle)."""
+def _train_steps_case(Bs, T, ragged, seed0=141, tf_ratio_mask=0.7):
+    """One D step (with the penalty) + one G step of the Trainer, both networks at H = 512 on the bf16 kernels, against the
+    oracle's step functions in fp64; returns (gpu D metrics, oracle D metrics, gpu G metrics, oracle G metrics)."""
     import generative_mouse_trajectories_amd as gmt
     over = dict(latent_dim=16, generator_hidden_dim=512, discriminator_hidden_dim=512)
     cfg = gmt.Config()
@@ -524,8 +530,8 @@ def test_bf16_train_steps_vs_fp64_oracle(ragged):
     cfg.lstm_dropout = cfg.head_dropout = 0.0
     cfg.compute_dtype = 'bf16'
     oc = O.OracleConfig(**over)
-    pg = PG.make_generator_params(oc, 141)
-    pd, bd = PG.make_discriminator_params(oc, 142)
+    pg = PG.make_generator_params(oc, seed0)
+    pd, bd = PG.make_discriminator_params(oc, seed0 + 1)
     G, D = gmt.Generator(cfg), gmt.Discriminator(cfg)
     G.load_state_dict({k: torch.from_numpy(v) for k, v in pg.items()}, strict=True)
     sd = {k: torch.from_numpy(v) for k, v in pd.items()}
@@ -533,15 +539,14 @@ def test_bf16_train_steps_vs_fp64_oracle(ragged):
     D.load_state_dict(sd, strict=True)
     tr = gmt.Trainer(G.to(DEV).train(), D.to(DEV).train(), cfg, torch.device(DEV), '/tmp/runs_gpu_bf16')
     tr.epoch = 30
-    Bs, T = 256, 16
-    lengths = np.random.default_rng(146).integers(T // 2, T + 1, Bs).tolist() if ragged else [T] * Bs   # ragged: also through the penalty
-    b = H.batch_t(Bs, T, 143, lengths, torch.float32)
+    lengths = np.random.default_rng(seed0 + 5).integers(T // 2, T + 1, Bs).tolist() if ragged else [T] * Bs   # ragged: also through the penalty
+    b = H.batch_t(Bs, T, seed0 + 2, lengths, torch.float32)
     b['sequences'][:, :, 2] *= 50.0
-    g = torch.Generator().manual_seed(144)
+    g = torch.Generator().manual_seed(seed0 + 3)
     nb = -(-Bs // 4)
     noise = {'z': torch.randn(Bs, 16, generator=g), 'gp_idx': torch.randperm(Bs, generator=g), 'alpha': torch.rand(nb, generator=g)}
     zg = torch.randn(Bs, 16, generator=g)
-    mask_tf = [bool(v) for v in (np.random.default_rng(145).random(T) < 0.7)]
+    mask_tf = [bool(v) for v in (np.random.default_rng(seed0 + 4).random(T) < tf_ratio_mask)]
     m_d = tr.train_discriminator_step(b, dict(noise))
     m_g = tr.train_generator_step(b, {'z': zg, 'tf_mask': mask_tf})
     dt = torch.float64
@@ -551,9 +556,21 @@ def test_bf16_train_steps_vs_fp64_oracle(ragged):
     bb = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in b.items()}
     md, _, _ = O.discriminator_step(Pg, Pd, Bd, {}, bb, {'z': noise['z'].to(dt), 'gp_idx': noise['gp_idx'], 'alpha': noise['alpha'].to(dt)}, oc, 0)
     mg, _, _ = O.generator_step(Pg, Pd, Bd, {}, bb, {'z': zg.to(dt)}, oc, mask_tf, tr.get_teacher_forcing_ratio())
-    print(f'ragged={ragged}')
+    print(f'B={Bs} T={T} ragged={ragged}')
     print('bf16 D step:', {k: (round(m_d[k], 5), round(float(v), 5)) for k, v in md.items()})
     print('bf16 G step:', {k: (round(m_g[k], 5), round(float(v), 5)) for k, v in mg.items()})
+    return dict(m_d), md, dict(m_g), mg
+
+
+@pytest.mark.parametrize('ragged', [False, True])
+def test_bf16_train_steps_vs_fp64_oracle(ragged):
+    """One full D step (with the gradient penalty on a quarter of the batch) and one G step of the Trainer with BOTH networks
+    at H = 512 on the bf16 kernels (BASELINE configs[2]'s width; T = 16, 256 full-length trajectories, time steps x 50 so the
+    features are O(1), dropout off for a deterministic comparison): every returned metric against the oracle's step functions
+    (RG.py:913-1118) in fp64.  Bars: 5e-2 on the Wasserstein / score / auxiliary-loss metrics (absolute floor 5e-3: the
+    untrained scores are ~1e-2), 1.5e-1 on the penalty (a squared gradient norm, which bf16 noise inflates - see
+    test_bf16_gradient_penalty_vs_fp64_oracle)."""
+    m_d, md, m_g, mg = _train_steps_case(256, 16, ragged)
     for got, ref in ((m_d, md), (m_g, mg)):
         for k, v in ref.items():
             bar = 1.5e-1 if k == 'd_gp' else 5e-2
