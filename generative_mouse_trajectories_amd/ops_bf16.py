@@ -26,6 +26,41 @@ from . import ops
 ROW_TILE = 256          # rows per workgroup tile of every bf16 kernel: batches are padded to a multiple of it
 BF16 = torch.bfloat16
 
+# ----------------------------------------------------------------------------------------------------------------------
+# row groups (include/gmt_hip.h, gmt_bf16_set_row_groups): the library's second chain of step launches lives on a stream
+# of its own, and a process has few hardware queues (GPU_MAX_HW_QUEUES = 4).  Round 2 met a run that never completed once
+# default-priority streams had filled them.  The default of two groups therefore only stands while
+# the process is known to hold few streams: as soon as a device-side process group (RCCL: communicator streams of its
+# own) is alive and nobody asked for a group count explicitly, layer calls run as ONE chain on the caller's stream.
+# ----------------------------------------------------------------------------------------------------------------------
+import os as _os
+
+_ROW_GROUPS_EXPLICIT = 'GMT_BF16_ROW_GROUPS' in _os.environ
+_ROW_GROUPS_POLICY = None       # what apply_row_group_policy last decided (None: not called yet)
+
+
+def set_row_groups(n: int) -> None:
+    """Explicit choice (1 or 2): overrides the policy below for the rest of the process."""
+    global _ROW_GROUPS_EXPLICIT
+    L_.call('gmt_bf16_set_row_groups', int(n))
+    _ROW_GROUPS_EXPLICIT = True
+
+
+def apply_row_group_policy() -> int:
+    """Called by the Trainer (construction and every bf16 step): one row group when a device-side process group is alive
+    and the count was not chosen explicitly, else the library's setting is left alone.  Returns the decision (0: left alone)."""
+    global _ROW_GROUPS_POLICY
+    if _ROW_GROUPS_EXPLICIT:
+        return 0
+    import torch.distributed as dist
+    crowded = dist.is_available() and dist.is_initialized() and any(
+        'nccl' in str(dist.get_backend(g)) for g in ([dist.group.WORLD] if dist.group.WORLD is not None else []))
+    want = 1 if crowded else 2
+    if want != _ROW_GROUPS_POLICY:
+        L_.call('gmt_bf16_set_row_groups', want)
+        _ROW_GROUPS_POLICY = want
+    return want
+
 _PERMS: dict = {}
 
 

@@ -24,6 +24,7 @@ from torch.optim.lr_scheduler import ReduceLROnPlateau
 
 from . import _lib as L_
 from . import ops
+from . import ops_bf16
 from .config import Config
 from .models import Discriminator, Generator, _pad_batch, trajectory_to_absolute
 
@@ -399,6 +400,7 @@ class Trainer:
         self.config = config
         self.device = device
         self.use_amp = False          # fp32 parity configuration
+        self._bf16 = getattr(config, 'compute_dtype', 'fp32') == 'bf16'
         self.scaler = None
         self.world_size = world_size
         self.process_group = process_group
@@ -575,6 +577,8 @@ class Trainer:
         noise = noise or {}
         cfg = self.config
         self.d_optimizer.zero_grad()
+        if self._bf16:
+            ops_bf16.apply_row_group_policy()
         starts, ends, sequences, lengths = self._to_dev(real_batch)
         batch_size, T = sequences.shape[0], sequences.shape[1]
         Bp = ops.pad_rows(batch_size, ops.row_tile(self.config))

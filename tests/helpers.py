@@ -61,3 +61,53 @@ def assert_close(a, b, rtol, name='', atol_frac=None):
     e = relerr(a, b)
     assert e <= rtol, f'{name}: rel err {e:.3e} > {rtol:.1e}'
     return e
+
+
+def curve_check(it, kind, got, ref_names, ref_vals, bar, exact=None):
+    """Config-1 loss curve (tests/golden/config1_curve.npz): a step's metrics against the reference's.  Scores, penalty and
+    auxiliary losses relative to their own size; d_loss is the difference of two scores that are ~100 x larger than it (an
+    untrained critic scores real and fake alike), so it is held to the same ABSOLUTE error as the scores it is made of.
+    exact (optional): the same step's metrics from the fp64 oracle.  Where the reference's own fp32 value is further than
+    `bar` from it - the penalty of a later iteration is such a quantity: clamps in the kinematic features make the critic's
+    input gradient discontinuous, 790.9 in the reference, 950.7 in fp64 - the value must be no further from the fp64 one than
+    1.25 x the reference is (the rule of test_gpu_parity._replay).  Returns the worst error / bar ratio among the metrics
+    held to `bar`."""
+    ref = dict(zip(list(ref_names), [float(v) for v in ref_vals]))
+    worst = 0.0
+    for k, v in ref.items():
+        scale = abs(v)
+        if k == 'd_loss':
+            scale = max(abs(ref['d_real_score']), abs(ref['d_fake_score']))
+        if k == 'g_loss':
+            scale = abs(ref['g_fake_score'])
+        scale = max(scale, 1e-3)
+        e = abs(float(got[k]) - v) / scale
+        if e > bar and exact is not None and abs(v - float(exact[k])) / scale > bar:
+            e_ref, e_got = abs(v - float(exact[k])) / scale, abs(float(got[k]) - float(exact[k])) / scale
+            assert e_got <= 1.25 * e_ref + bar, (f'iteration {it} {kind} step, {k}: {got[k]} is {e_got:.2e} from the fp64 oracle '
+                                                 f'({exact[k]}), the reference ({v}) {e_ref:.2e}')
+            continue
+        worst = max(worst, e / bar)
+        assert e <= bar, f'iteration {it} {kind} step, {k}: {got[k]} vs {v} (error {e:.2e} of scale, bar {bar:.1e})'
+    return worst
+
+
+def curve_oracle64(g, n_iter):
+    """The fp64 oracle's metrics for the first n_iter iterations of the config-1 curve: [(D metrics, G metrics)]."""
+    import torch
+    from oracle import gan_oracle as O
+    dt = torch.float64
+    cfg, Pg, Pd, Bd = oracle_models(DEFAULT, 301, 302, dt)
+    opt_g, opt_d, out = {}, {}, []
+    cv = lambda v: v.to(dt) if v.dtype.is_floating_point else v
+    for it in range(n_iter):
+        batch = {k: cv(t(g[f'it{it}_batch/{k}'])) for k in ('starts', 'ends', 'sequences', 'lengths')}
+        noise = {'z': cv(t(g[f'it{it}_D_z']))}
+        if f'it{it}_D_alpha' in g:
+            noise['alpha'] = cv(t(g[f'it{it}_D_alpha']))
+            noise['gp_idx'] = t(g[f'it{it}_D_gp_idx'])
+        md, _, _ = O.discriminator_step(Pg, Pd, Bd, opt_d, batch, noise, cfg, it)
+        ratio = O.teacher_forcing_ratio(int(g['epochs'][it]), cfg)
+        mg, _, _ = O.generator_step(Pg, Pd, Bd, opt_g, batch, {'z': cv(t(g[f'it{it}_G_z']))}, cfg, list(g[f'it{it}_G_tf_mask']), ratio)
+        out.append((md, mg))
+    return out

@@ -150,3 +150,27 @@ def test_fp64_oracle_agrees_with_fp32():
     g = H.load('tiny_modules.npz')
     seq = O.generator_forward(Pg, b['starts'], b['ends'], H.t(g['tiny_z'], torch.float64), b['sequences'], [False] * 9)
     H.assert_close(seq.float(), g['tiny_gfwd_tf0'], 2e-5, 'fp64 G fwd')
+
+
+def test_config1_loss_curve_first_iterations():
+    """BASELINE configs[0]: the reference trained on its own recording (data/mouse_data_20250813_235208.csv) with default
+    hyper-parameters, B = 32 - tests/golden/config1_curve.npz holds its batches, noise and per-iteration metrics
+    (tests/golden/make_config1_golden.py).  The oracle's step functions replay the first 3 of the 8 iterations here (CPU
+    time); the GPU suite replays all 8 through the Trainer."""
+    g = H.load('config1_curve.npz')
+    cfg, Pg, Pd, Bd = H.oracle_models(H.DEFAULT, 301, 302)
+    opt_g, opt_d = {}, {}
+    for it in range(3):
+        batch = {k: H.t(g[f'it{it}_batch/{k}']) for k in ('starts', 'ends', 'sequences', 'lengths')}
+        noise = {'z': H.t(g[f'it{it}_D_z'])}
+        if f'it{it}_D_alpha' in g:
+            noise['alpha'] = H.t(g[f'it{it}_D_alpha'])
+            noise['gp_idx'] = H.t(g[f'it{it}_D_gp_idx'])
+        # 1e-4 on the same weights (iteration 0); once both sides have taken their own Adam steps the bar is 5e-4 (the
+        # oracle - CPU torch like the reference, another association of the same sums - is 1.4e-4 off at iteration 1)
+        bar = 1e-4 if it == 0 else 5e-4
+        m, _, _ = O.discriminator_step(Pg, Pd, Bd, opt_d, batch, noise, cfg, it)
+        H.curve_check(it, 'D', m, g[f'it{it}_D_metric_names'], g[f'it{it}_D_metrics'], bar)
+        ratio = O.teacher_forcing_ratio(int(g['epochs'][it]), cfg)
+        m, _, _ = O.generator_step(Pg, Pd, Bd, opt_g, batch, {'z': H.t(g[f'it{it}_G_z'])}, cfg, list(g[f'it{it}_G_tf_mask']), ratio)
+        H.curve_check(it, 'G', m, g[f'it{it}_G_metric_names'], g[f'it{it}_G_metrics'], bar)

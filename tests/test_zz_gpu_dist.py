@@ -49,14 +49,62 @@ def test_overlapped_bucketed_allreduce_is_the_same_step(tmp_path):
             assert all(tr2._d_sync.launched) and all(tr2._g_sync.launched)
         for nm, a, b in (('G params', tr1.g_flat.flat, tr2.g_flat.flat), ('D params', tr1.d_flat.flat, tr2.d_flat.flat),
                          ('G grads', tr1.g_flat.grad, tr2.g_flat.grad), ('D grads', tr1.d_flat.grad, tr2.d_flat.grad)):
-            # D: bitwise - none of its kernels accumulates with atomics (own split-K kernels with an ordered slab
-            # reduction) and a sum all-reduce over one rank changes nothing.  G: last-bit differences in a few hundred
-            # elements - the condition encoder (RG.py:440-447) is still torch ops whose library backward kernels
-            # (GEMM / LayerNorm) are not run-to-run deterministic, two runs of the SAME trainer differ alike
-            if nm.startswith('D'):
-                assert torch.equal(a, b), (nm, float((a - b).abs().max()), int((a != b).sum()), a.numel())
+            # not bitwise: the hand-written kernels are deterministic (ordered split-K slab reduction, no float atomics,
+            # no library GEMM on the step), but the torch ops still on the path are not run to run - the condition
+            # encoder's library backward (G: a few hundred last-bit differences) and the penalty's twice-differentiated
+            # torch front end (D: measured 2 of 181 060 elements, 5e-10) - two runs of the SAME trainer differ alike
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (nm, float((a - b).abs().max()), int((a != b).sum()), a.numel())
     finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_trainer_with_rccl_group_overlap_and_two_row_groups_completes(tmp_path):
+    """Round 2's stall was a stream COUNT (default stream + three default-priority library streams, then a two-stream
+    sequence never completed).  The same count is within reach without a fourth row group: default
+    stream + the library's row-group stream + an RCCL communicator's streams + Trainer._side.  This is that combination:
+    bf16 Trainer (H = 512), one-rank RCCL group alive, overlap_g_forward on; first the library's policy (one row group
+    while a device-side process group is alive and nobody chose), then two row groups chosen explicitly - two iterations
+    each must complete (pytest's timeout is the verdict on a stall) with finite metrics."""
+    import generative_mouse_trajectories_amd as gmt
+    from generative_mouse_trajectories_amd import ops_bf16
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    port = 27000 + os.getpid() % 4000
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=DEV)
+    was_explicit = ops_bf16._ROW_GROUPS_EXPLICIT
+    try:
+        cfg = gmt.Config()
+        cfg.latent_dim, cfg.generator_hidden_dim, cfg.discriminator_hidden_dim = 16, 512, 512
+        cfg.compute_dtype = 'bf16'
+        torch.manual_seed(0)
+        tr = gmt.Trainer(gmt.Generator(cfg), gmt.Discriminator(cfg), cfg, DEV, log_dir=str(tmp_path / 'r'), world_size=2,
+                         process_group=dist.group.WORLD)
+        tr.g_optimizer.grad_scale = tr.d_optimizer.grad_scale = 1.0
+        tr.overlap_g_forward = True
+        tr.generator.train(); tr.discriminator.train()
+        B, T = 1024, 12
+        g = torch.Generator().manual_seed(1)
+        deltas = torch.randn(B, T, 2, generator=g) * 0.01
+        starts = torch.rand(B, 2, generator=g)
+        batch = {'starts': starts.to(DEV), 'ends': (starts + deltas.sum(1)).to(DEV),
+                 'sequences': torch.cat([deltas, torch.rand(B, T, 1, generator=g) + 0.2], -1).to(DEV),
+                 'lengths': torch.full((B,), T, dtype=torch.long, device=DEV)}
+        ops_bf16._ROW_GROUPS_EXPLICIT = False
+        ops_bf16._ROW_GROUPS_POLICY = None
+        assert ops_bf16.apply_row_group_policy() == 1          # a device-side group is alive and nobody chose
+        for groups in (None, 2):
+            if groups is not None:
+                ops_bf16.set_row_groups(groups)                # explicit: the policy stands back
+                assert ops_bf16.apply_row_group_policy() == 0
+            for it in range(2):
+                md = dict(tr.train_discriminator_step(batch))
+                mg = dict(tr.train_generator_step(batch))
+                assert all(v == v and abs(v) < 1e6 for v in list(md.values()) + list(mg.values())), (groups, it, md, mg)
+        torch.cuda.synchronize()
+    finally:
+        ops_bf16._ROW_GROUPS_EXPLICIT = was_explicit
+        ops_bf16._ROW_GROUPS_POLICY = None
+        ops_bf16.L_.call('gmt_bf16_set_row_groups', 2)
         dist.destroy_process_group()
 
 
