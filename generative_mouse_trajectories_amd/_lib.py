@@ -65,6 +65,8 @@ _SIGS = {
     'gmt_version': [],
     'gmt_kinematics_fwd': [c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     'gmt_kinematics_bwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    'gmt_kinematics_jvp': [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    'gmt_lrelu_mask_mul': [c_p, c_p, c_p, c_f, c_ll, c_p],
     'gmt_telemetry_kinematics_f64': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_d, c_d, c_p],
     'gmt_telemetry_derived_f64': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_p],
     'gmt_adam_step': [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_f, c_p],

@@ -37,6 +37,9 @@ def kinematics_torch(pos: torch.Tensor, dts: torch.Tensor, eps: float = 1e-8) ->
                         jerk.clamp(-10000, 10000), curv.clamp(0, 100)], dim=-1)
 
 
+GP_KERNEL_FRONT_END = True      # False: the torch-composite front end (kept for widths the kernels do not cover, and as an A/B switch)
+
+
 def discriminator_forward_gp(D, trajectories: torch.Tensor, dts: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
     """Twice-differentiable discriminator forward for the gradient penalty: the BiLSTM runs in
     the HIP kernels (ops.LSTMLayerGPFn: forward, first backward and the second-order sweep
@@ -53,7 +56,16 @@ def discriminator_forward_gp(D, trajectories: torch.Tensor, dts: torch.Tensor, l
     d = _pad_batch(dts.transpose(0, 1), Bp, 1)
     lens = _pad_batch(lengths.to(device=trajectories.device, dtype=torch.int32).clamp(min=1), Bp, 0, 1).contiguous()
     sn_w = D.spectral_weights()
-    x = D.run_sequential(D.feature_encoder, kinematics_torch(pos, d), sn_w)
+    fe = D.feature_encoder
+    H = cfg.discriminator_hidden_dim
+    if (GP_KERNEL_FRONT_END and not getattr(D, 'bf16', False) and ops.encoder_gp_supported(H)
+            and fe[3].negative_slope == fe[1].negative_slope):
+        # kinematics + both Linears + both LeakyReLUs in one launch, twice differentiable through hand-written
+        # first / second backward passes (ops.EncoderGPFn): no torch composite on the fp32 penalty path
+        w1, w2 = sn_w.pop(0), sn_w.pop(0)
+        x = ops.encoder_gp(pos.contiguous(), d.contiguous(), w1, fe[0].bias, w2, fe[2].bias, float(fe[1].negative_slope), 1e-8)
+    else:
+        x = D.run_sequential(D.feature_encoder, kinematics_torch(pos, d), sn_w)
     nl = cfg.discriminator_num_layers
     if getattr(D, 'bf16', False):
         # H = 512 (BASELINE configs[2]): the whole BiLSTM stack is ONE twice-differentiable op on the bf16 step kernels

@@ -115,8 +115,14 @@ void dx_gemm_res_kernel(const float* __restrict__ dA, const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lo = lane & 31;
-    const int nb = blockIdx.x % n_nb;
-    const long long worker = blockIdx.x / n_nb, workers = gridDim.x / n_nb;
+    // The n_nb column blocks of one worker read the SAME dA tiles.  Workgroups go to the 8 XCDs round-robin
+    // (blockIdx % 8), each XCD with an L2 of its own: the blocks of a worker are therefore given indices 8 apart - same
+    // XCD, dispatched back to back - so that the second reader of a tile finds it in that L2 (round 3 counters: with
+    // neighbouring indices the fabric carried dA twice, 4.88 GB for 2.16 GB of dA at K512 / N256).
+    const long long workers = gridDim.x / n_nb;
+    const bool xcd_pairs = (n_nb > 1) && (workers % 8 == 0);
+    const int nb = xcd_pairs ? (int)((blockIdx.x / 8) % n_nb) : (int)(blockIdx.x % n_nb);
+    const long long worker = xcd_pairs ? (long long)(blockIdx.x / (8 * n_nb)) * 8 + blockIdx.x % 8 : blockIdx.x / n_nb;
     if (worker >= n_tiles) return;
     const long long last_tile = worker + ((n_tiles - 1 - worker) / workers) * workers;   // this worker's final tile
     // addressing: one uniform base per tile (scalar registers) + ONE per-lane offset per buffer, laundered at each use

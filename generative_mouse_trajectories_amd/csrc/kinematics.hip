@@ -24,8 +24,10 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// JVP = true: the forward-mode derivative instead (kin_jvp_vals: feature tangents for the position tangents phat).
+template <bool JVP>
 __global__ __launch_bounds__(KB)
-void kin_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ dts,
+void kin_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ dts, const float* __restrict__ phat,
                     float* __restrict__ feat, int L, int B, float eps, int kch)
 {
     __shared__ float4 stage4[KB / 64][64 * 9 / 4];
@@ -40,7 +42,8 @@ void kin_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ dts
         const long long base = (long long)t * B + bw;
         if (lane < nbw) {
             float o[9];
-            gmt_kin::kin_fwd_vals(base + lane, pos, dts, o, L, B, eps);
+            if constexpr (JVP) gmt_kin::kin_jvp_vals(base + lane, pos, dts, phat, o, L, B, eps);
+            else gmt_kin::kin_fwd_vals(base + lane, pos, dts, o, L, B, eps);
 #pragma unroll
             for (int c = 0; c < 9; ++c) stage[lane * 9 + c] = o[c];
         }
@@ -136,7 +139,40 @@ extern "C" int gmt_kinematics_fwd(const float* pos, const float* dts, float* fea
 {
     GMT_CHECK_ARG(pos && dts && feat && L >= 1 && B >= 1);
     const int kch = kin_chunk(L, B);
-    hipLaunchKernelGGL(kin_fwd_kernel, dim3((B + KB - 1) / KB, (L + kch - 1) / kch), dim3(KB), 0, stream, pos, dts, feat, L, B, eps, kch);
+    hipLaunchKernelGGL(kin_fwd_kernel<false>, dim3((B + KB - 1) / KB, (L + kch - 1) / kch), dim3(KB), 0, stream, pos, dts, nullptr, feat, L, B, eps, kch);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+extern "C" int gmt_kinematics_jvp(const float* pos, const float* dts, const float* phat, float* fhat,
+                                  int L, int B, float eps, hipStream_t stream)
+{
+    GMT_CHECK_ARG(pos && dts && phat && fhat && L >= 1 && B >= 1);
+    const int kch = kin_chunk(L, B);
+    hipLaunchKernelGGL(kin_fwd_kernel<true>, dim3((B + KB - 1) / KB, (L + kch - 1) / kch), dim3(KB), 0, stream, pos, dts, phat, fhat, L, B, eps, kch);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+namespace {
+// out[i] = g[i] * (act[i] > 0 ? 1 : slope): the LeakyReLU derivative as a mask (float4 lanes, n % 4 == 0)
+__global__ __launch_bounds__(256)
+void lrelu_mask_mul_kernel(const float4* __restrict__ g, const float4* __restrict__ act, float4* __restrict__ out, float slope, long long n4)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = act[i], v = g[i];
+        out[i] = make_float4(v.x * (a.x > 0.f ? 1.f : slope), v.y * (a.y > 0.f ? 1.f : slope),
+                             v.z * (a.z > 0.f ? 1.f : slope), v.w * (a.w > 0.f ? 1.f : slope));
+    }
+}
+}  // namespace
+
+extern "C" int gmt_lrelu_mask_mul(const float* g, const float* act, float* out, float slope, long long n, hipStream_t stream)
+{
+    GMT_CHECK_ARG(g && act && out && n >= 4 && (n % 4) == 0);
+    GMT_CHECK_ARG((((uintptr_t)g | (uintptr_t)act | (uintptr_t)out) & 15) == 0);
+    hipLaunchKernelGGL(lrelu_mask_mul_kernel, dim3(gmt_grid_1d(n / 4, 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(act), reinterpret_cast<float4*>(out), slope, n / 4);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }

@@ -208,6 +208,91 @@ GMT_HD void kin_bwd_vals(long long idx, const float* pos, const float* dts, Grad
     gx_out = gx; gy_out = gy; gd_out = gd;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Forward-mode derivative of the features w.r.t. the positions: fhat[t] = J_t(pos, dts) . phat  (dts fixed).
+// This is the kinematics piece of the gradient penalty's SECOND backward (RG.py:829-835: autograd.grad with
+// create_graph=True differentiates the first backward, gpos = J^T gfeat, once more; the adjoint of gfeat in
+// that map is J phat with phat = the adjoint of gpos).  The interpolated positions are a leaf that no
+// parameter feeds, so the adjoint of pos itself (the Hessian term) is never needed.  Same formulas as
+// kin_fwd_vals in dual numbers; a clamp passes a tangent exactly where kin_bwd_vals passes a gradient
+// (value inside the closed interval).
+// ------------------------------------------------------------------------------------------------------------
+struct Du { float v, d; };
+GMT_HD Du du_add(Du a, Du b) { return Du{a.v + b.v, a.d + b.d}; }
+GMT_HD Du du_sub(Du a, Du b) { return Du{a.v - b.v, a.d - b.d}; }
+GMT_HD Du du_mul(Du a, Du b) { return Du{a.v * b.v, a.d * b.v + a.v * b.d}; }
+GMT_HD Du du_addf(Du a, float c) { return Du{a.v + c, a.d}; }
+GMT_HD Du du_divf(Du a, float c) { return Du{GMT_DIV(a.v, c), GMT_DIV(a.d, c)}; }
+GMT_HD Du du_div(Du a, Du b) { const float q = GMT_DIV(a.v, b.v); return Du{q, GMT_DIV(a.d - q * b.d, b.v)}; }
+GMT_HD Du du_sqrt(Du a) { const float r = sqrtf(a.v); return Du{r, GMT_DIV(0.5f * a.d, r)}; }
+GMT_HD float du_clamp_tan(Du a, float lo, float hi) { return (a.v >= lo && a.v <= hi) ? a.d : 0.0f; }
+
+struct PtD { Du dx, dy, vel, vx, vy; };
+
+GMT_HD PtD make_ptd(Du x, Du y, Du xp, Du yp, float d, bool has_prev, float eps) {
+    PtD p;
+    const Du z{0.0f, 0.0f};
+    p.dx = has_prev ? du_sub(x, xp) : z;
+    p.dy = has_prev ? du_sub(y, yp) : z;
+    const float td = d + eps;
+    const Du disp = du_sqrt(du_addf(du_add(du_mul(p.dx, p.dx), du_mul(p.dy, p.dy)), eps));
+    p.vel = du_divf(disp, td);
+    p.vx = du_divf(p.dx, td);
+    p.vy = du_divf(p.dy, td);
+    return p;
+}
+
+GMT_HD void kin_jvp_vals(long long idx, const float* pos, const float* dts, const float* phat, float (&o)[9],
+                         int L, int B, float eps)
+{
+    const int t = (int)(idx / B);
+    Du x[4], y[4];
+    float d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int tt = t - 3 + k;
+        long long j = idx - (long long)(3 - k) * B;
+        if (tt < 0) j = idx - (long long)t * B;
+        const F2 p = reinterpret_cast<const F2*>(pos)[j];
+        const F2 h = reinterpret_cast<const F2*>(phat)[j];
+        x[k] = Du{p.x, h.x}; y[k] = Du{p.y, h.y}; d[k] = dts[j];
+    }
+    const PtD p0 = make_ptd(x[3], y[3], x[2], y[2], d[3], t >= 1, eps);
+    const PtD p1 = make_ptd(x[2], y[2], x[1], y[1], d[2], t >= 2, eps);
+    const PtD p2 = make_ptd(x[1], y[1], x[0], y[0], d[1], t >= 3, eps);
+    const Du z{0.0f, 0.0f};
+    Du acc = z, jerk = z, ax = z, ay = z;
+    if (t >= 1) {
+        const float m = (d[3] + d[2]) * 0.5f + eps;
+        acc = du_divf(du_sub(p0.vel, p1.vel), m);
+        ax = du_divf(du_sub(p0.vx, p1.vx), m);
+        ay = du_divf(du_sub(p0.vy, p1.vy), m);
+        if (t >= 2) {
+            const float mp = (d[2] + d[1]) * 0.5f + eps;
+            const Du accp = du_divf(du_sub(p1.vel, p2.vel), mp);
+            jerk = du_divf(du_sub(acc, accp), m + eps);
+        }
+    }
+    const Du u = du_addf(du_add(du_mul(p0.vx, p0.vx), du_mul(p0.vy, p0.vy)), eps);
+    const Du q = du_sub(du_mul(p0.vx, ay), du_mul(p0.vy, ax));
+    const float sgn = q.v > 0.f ? 1.f : (q.v < 0.f ? -1.f : 0.f);
+    const Du cross{fabsf(q.v), sgn * q.d};
+    const Du curv = du_div(cross, du_mul(u, du_sqrt(u)));
+    o[0] = x[3].d; o[1] = y[3].d; o[2] = p0.dx.d; o[3] = p0.dy.d; o[4] = 0.0f;
+    o[5] = du_clamp_tan(p0.vel, 0.f, 100.f);
+    o[6] = du_clamp_tan(acc, -1000.f, 1000.f);
+    o[7] = du_clamp_tan(jerk, -10000.f, 10000.f);
+    o[8] = du_clamp_tan(curv, 0.f, 100.f);
+}
+
+GMT_HD void kin_jvp_point(long long idx, const float* pos, const float* dts, const float* phat, float* fhat,
+                          int L, int B, float eps)
+{
+    float o[9];
+    kin_jvp_vals(idx, pos, dts, phat, o, L, B, eps);
+    for (int c = 0; c < 9; ++c) fhat[idx * 9 + c] = o[c];
+}
+
 struct GradFromMemory {
     const float* gfeat; long long idx; int B;
     GMT_HDM float operator()(int k, int c) const { return gfeat[(idx + (long long)k * B) * 9 + c]; }

@@ -604,6 +604,120 @@ class EncoderFn(torch.autograd.Function):
         return gpos, gdts, d_w1, d_b1, d_w2, d_b2, None, None, None
 
 
+def lrelu_mask_mul(g: torch.Tensor, act: torch.Tensor, slope: float) -> torch.Tensor:
+    """g * LeakyReLU'(act), one launch (csrc/kinematics.hip)."""
+    g, act = g.contiguous(), act.contiguous()
+    out = torch.empty_like(g)
+    L_.call('gmt_lrelu_mask_mul', L_.ptr(g), L_.ptr(act), L_.ptr(out), float(slope), g.numel(), L_.stream(), label='skip')
+    return out
+
+
+class EncoderBwdGPFn(torch.autograd.Function):
+    """The FIRST backward of the critic's front end as a differentiable op (gradient penalty, RG.py:829-835):
+    (g = adjoint of e, the forward's saved pos / dts / h1 / e, the two normalised weights) -> gpos.
+        d_pre2 = g * lrelu'(e);  d_pre1 = (d_pre2 W2) * lrelu'(h1);  gfeat = d_pre1 W1;  gpos = J^T gfeat
+    Every map is linear in g, so its backward - the front end's share of the second-order sweep - is the same chain
+    transposed, all on existing kernels plus the kinematics JVP:
+        fhat = J phat (gmt_kinematics_jvp);  a1 = (fhat W1^T) * lrelu'(h1);  ghat = (a1 W2^T) * lrelu'(e)  (gmt_dx_gemm)
+        W1hat = d_pre1^T fhat,  W2hat = d_pre2^T a1  (gmt_wgrad).
+    The interpolated positions are a leaf no parameter feeds and the masks are piecewise constant: neither gets an
+    adjoint."""
+
+    @staticmethod
+    def forward(ctx, g, pos, dts, h1, e, w1, w2, slope, eps):
+        L, B = dts.shape
+        H = w1.shape[0]
+        R = L * B
+        d_pre2 = lrelu_mask_mul(g.reshape(R, H), e.view(R, H), slope)
+        d_pre1 = dx_gemm(d_pre2, pack_dx_weight(w2.detach().contiguous()), H, H, h1.view(R, H), slope)
+        gfeat = torch.mm(d_pre1, w1.detach())                       # [R, 9]
+        gpos = torch.empty_like(pos)
+        gdts = torch.empty_like(dts)
+        L_.call('gmt_kinematics_bwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(gfeat), L_.ptr(gpos), L_.ptr(gdts),
+                L, B, eps, L_.stream(), nbytes=60.0 * L * B)
+        ctx.save_for_backward(pos, dts, h1, e, w1, w2, d_pre1, d_pre2)
+        ctx.cfg = (float(slope), float(eps))
+        return gpos
+
+    @staticmethod
+    def backward(ctx, phat):
+        pos, dts, h1, e, w1, w2, d_pre1, d_pre2 = ctx.saved_tensors
+        slope, eps = ctx.cfg
+        L, B = dts.shape
+        H = w1.shape[0]
+        R = L * B
+        phat = phat.contiguous()
+        fhat = torch.empty(L, B, 9, device=pos.device, dtype=torch.float32)
+        L_.call('gmt_kinematics_jvp', L_.ptr(pos), L_.ptr(dts), L_.ptr(phat), L_.ptr(fhat), L, B, eps, L_.stream(),
+                nbytes=56.0 * L * B)
+        fh = fhat.view(R, 9)
+        a1 = lrelu_mask_mul(torch.mm(fh, w1.detach().t()), h1.view(R, H), slope)
+        ghat = dx_gemm(a1, pack_dx_weight(w2.detach().t().contiguous()), H, H, e.view(R, H), slope)
+        w1hat = w2hat = None
+        if ctx.needs_input_grad[5]:
+            w1hat = wgrad(d_pre1, fh)[0]
+        if ctx.needs_input_grad[6]:
+            w2hat = wgrad(d_pre2, a1)[0]
+        return ghat.view(L, B, H), None, None, None, None, w1hat, w2hat, None, None
+
+
+class EncoderGPFn(torch.autograd.Function):
+    """Twice-differentiable critic front end of the gradient-penalty pass: the same launch as EncoderFn (kinematics +
+    both spectral-norm Linears + both LeakyReLUs, gmt_encoder_fwd).  Its backward under create_graph=True (the
+    penalty's autograd.grad w.r.t. the interpolated positions) is EncoderBwdGPFn; the ordinary backward that follows
+    the second-order sweep yields the weight / bias gradients only (the positions are a leaf of the inner grad)."""
+
+    @staticmethod
+    def forward(ctx, pos, dts, w1, b1, w2, b2, slope, eps):
+        L_.require_cuda(pos, dts, w1, w2)
+        pos, dts = pos.contiguous().float(), dts.contiguous().float()
+        L, B = dts.shape
+        H = w1.shape[0]
+        assert B % TM == 0 and w1.shape == (H, 9) and w2.shape == (H, H)
+        dev = pos.device
+        NW = H // 32
+        w1_pk = _pack1(w1, 16, 9, 1 << 30, NW, 1, 0, 1, 9)
+        w2_pk = _pack1(w2, H, H, 1 << 30, NW, 1, 0, 1, H)
+        e = torch.empty(L, B, H, device=dev, dtype=torch.float32)
+        feat = torch.empty(L, B, 9, device=dev, dtype=torch.float32)
+        h1 = torch.empty(L, B, H, device=dev, dtype=torch.float32)
+        L_.call('gmt_encoder_fwd', L_.ptr(pos), L_.ptr(dts), L_.ptr(w1_pk), L_.ptr(b1.detach().contiguous()),
+                L_.ptr(w2_pk), L_.ptr(b2.detach().contiguous()), L_.ptr(feat), L_.ptr(h1), L_.ptr(e), L, B, H,
+                float(eps), float(slope), L_.stream(), label='encoder_fwd_gp', flops=2.0 * L * B * (9 * H + H * H))
+        ctx.save_for_backward(pos, dts, feat, h1, e, w1, w2)
+        ctx.cfg = (float(slope), float(eps))
+        return e
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, dts, feat, h1, e, w1, w2 = ctx.saved_tensors
+        slope, eps = ctx.cfg
+        L, B = dts.shape
+        H = w1.shape[0]
+        R = L * B
+        if torch.is_grad_enabled():
+            gpos = EncoderBwdGPFn.apply(g, pos, dts, h1, e, w1, w2, slope, eps)
+            return gpos, None, None, None, None, None, None, None
+        gq = lrelu_mask_mul(g.reshape(R, H), e.view(R, H), slope)
+        h1v = h1.view(R, H)
+        d_w2 = d_b2 = d_w1 = d_b1 = None
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
+            d_w2, d_b2 = wgrad(gq, h1v, want_db=True)
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            d_pre1 = dx_gemm(gq, pack_dx_weight(w2.detach().contiguous()), H, H, h1v, slope)
+            d_w1, d_b1 = wgrad(d_pre1, feat.view(R, 9), want_db=True)
+        return None, None, d_w1, d_b1, d_w2, d_b2, None, None
+
+
+def encoder_gp(pos, dts, w1, b1, w2, b2, slope: float = 0.2, eps: float = 1e-8):
+    return EncoderGPFn.apply(pos, dts, w1, b1, w2, b2, slope, eps)
+
+
+def encoder_gp_supported(H: int) -> bool:
+    """Shapes the kernelised penalty front end covers: gmt_encoder_fwd's widths and gmt_dx_gemm's (H, H) table."""
+    return H % 32 == 0 and H <= 256 and _dx_shape_ok(H, H)
+
+
 def encoder(pos, dts, w1, b1, w2, b2, slope: float = 0.2, eps: float = 1e-8, grad_is_preact: bool = False):
     return EncoderFn.apply(pos, dts, w1, b1, w2, b2, slope, eps, grad_is_preact)
 

@@ -55,6 +55,15 @@ int gmt_kinematics_fwd(const float* pos, const float* dts, float* feat,
 int gmt_kinematics_bwd(const float* pos, const float* dts, const float* gfeat,
                        float* gpos, float* gdts, int L, int B, float eps, hipStream_t stream);
 
+/* Forward-mode derivative of the same features w.r.t. the positions (dts fixed): phat [L][B][2] -> fhat [L][B][9] =
+ * J(pos, dts) phat.  The kinematics piece of the second backward of compute_gradient_penalty (RG.py:829-835,
+ * create_graph=True): the adjoint of gfeat in gpos = J^T gfeat.  Clamped features pass no tangent, as in _bwd. */
+int gmt_kinematics_jvp(const float* pos, const float* dts, const float* phat, float* fhat,
+                       int L, int B, float eps, hipStream_t stream);
+/* out = g * LeakyReLU'(act) element-wise (n % 4 == 0, 16-byte aligned): the activation masks of the feature encoder
+ * (RG.py:714, 716) in the penalty's first and second backward, where they cannot ride in a GEMM epilogue. */
+int gmt_lrelu_mask_mul(const float* g, const float* act, float* out, float slope, long long n, hipStream_t stream);
+
 /* ---- fused critic front end ----------------------------------------------------------------
  * Replaces compute_kinematics (RG.py:315-389, called at RG.py:757) + Discriminator.feature_encoder
  * (RG.py:712-717, applied at RG.py:761) in one launch: pos [L][B][2], dts [L][B] ->

@@ -12,6 +12,9 @@ extern "C" {
 void sim_kin_fwd(const float* pos, const float* dts, float* feat, int L, int B, float eps) {
     for (long long i = 0; i < (long long)L * B; ++i) gmt_kin::kin_fwd_point(i, pos, dts, feat, L, B, eps);
 }
+void sim_kin_jvp(const float* pos, const float* dts, const float* phat, float* fhat, int L, int B, float eps) {
+    for (long long i = 0; i < (long long)L * B; ++i) gmt_kin::kin_jvp_point(i, pos, dts, phat, fhat, L, B, eps);
+}
 void sim_kin_bwd(const float* pos, const float* dts, const float* gfeat, float* gpos, float* gdts,
                  int L, int B, float eps) {
     for (long long i = 0; i < (long long)L * B; ++i) gmt_kin::kin_bwd_point(i, pos, dts, gfeat, gpos, gdts, L, B, eps);

@@ -46,6 +46,38 @@ def test_kinematics_bodies(sim):
         H.assert_close(gdts.T, g[f'kin_{name}_gdts'], 2e-5, f'gdts {name}')
 
 
+def test_kinematics_jvp_against_fp64_oracle(sim):
+    """kin_jvp_vals (the kinematics piece of the gradient penalty's second backward): fhat = J(pos, dts) phat against
+    torch.autograd.functional.jvp of the oracle's compute_kinematics restatement in fp64, and the adjoint identity
+    <gfeat, J phat> = <J^T gfeat, phat> against the backward body (the pair the penalty differentiates through)."""
+    rng = np.random.default_rng(5)
+    B, L = 9, 37
+    pos = (rng.uniform(0, 1, (B, 1, 2)) + np.cumsum(rng.normal(0, 0.01, (B, L, 2)), 1)).astype(np.float32)
+    dts = rng.uniform(0.002, 0.03, (B, L)).astype(np.float32)
+    dts[:, 5] *= 20.0                                   # a few slow steps: some features inside, some outside their clamps
+    phat = rng.normal(size=(B, L, 2)).astype(np.float32)
+    p64, d64 = torch.tensor(pos, dtype=torch.float64), torch.tensor(dts, dtype=torch.float64)
+    _, ref = torch.autograd.functional.jvp(lambda q: O.kinematics(q, d64), (p64,), (torch.tensor(phat, dtype=torch.float64),))
+    pos_t = np.ascontiguousarray(pos.transpose(1, 0, 2)); dts_t = np.ascontiguousarray(dts.T)
+    ph_t = np.ascontiguousarray(phat.transpose(1, 0, 2))
+    fhat = np.zeros((L, B, 9), np.float32)
+    sim.sim_kin_jvp(fp(pos_t), fp(dts_t), fp(ph_t), fp(fhat), L, B, ctypes.c_float(1e-8))
+    got = fhat.transpose(1, 0, 2)
+    feat = O.kinematics(p64, d64).numpy()
+    inside = np.ones_like(got, dtype=bool)              # compare where the fp64 feature is clear of a clamp boundary
+    for c, (lo, hi) in {5: (0, 100), 6: (-1000, 1000), 7: (-10000, 10000), 8: (0, 100)}.items():
+        inside[:, :, c] = (np.abs(feat[:, :, c] - lo) > 1e-3 * (hi - lo)) & (np.abs(feat[:, :, c] - hi) > 1e-3 * (hi - lo))
+    assert inside.mean() > 0.9 and (feat[:, :, 7] == 10000).any()
+    for c in range(9):
+        r, gt = ref.numpy()[:, :, c][inside[:, :, c]], got[:, :, c][inside[:, :, c]]
+        assert np.abs(gt - r).max() <= 2e-4 * max(np.abs(r).max(), 1e-30), (c, np.abs(gt - r).max(), np.abs(r).max())
+    w = rng.normal(size=(B, L, 9)).astype(np.float32)
+    gpos = np.zeros((L, B, 2), np.float32); gdts = np.zeros((L, B), np.float32)
+    sim.sim_kin_bwd(fp(pos_t), fp(dts_t), fp(np.ascontiguousarray(w.transpose(1, 0, 2))), fp(gpos), fp(gdts), L, B, ctypes.c_float(1e-8))
+    lhs = float((w.astype(np.float64) * got).sum()); rhs = float((gpos.transpose(1, 0, 2).astype(np.float64) * phat).sum())
+    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs)), (lhs, rhs)
+
+
 def test_kinematics_bwd_against_fp64_oracle(sim):
     rng = np.random.default_rng(3)
     B, L = 7, 40
