@@ -195,7 +195,10 @@ class Generator(nn.Module):
             w_ih0 = lp.weight_ih_l0
             g0 = F.linear(cond, w_ih0[:, 3:3 + H], lp.bias_ih_l0 + lp.bias_hh_l0)
             w_u = torch.cat([w_ih0[:, :3], w_ih0[:, 3 + H:]], dim=1)
-            tf_list = None if tf_mask is None else [bool(v) for v in tf_mask.tolist()]
+            # (the host's copy of the coins when the caller kept one - forward_tm / forward do: no device read-back)
+            tf_list = getattr(tf_mask, 'gmt_host_list', None) if tf_mask is not None else None
+            if tf_mask is not None and tf_list is None:
+                tf_list = [bool(v) for v in tf_mask.tolist()]
             out = ops_bf16.GenRolloutBf16Fn.apply(g0, w_u, lp.weight_hh_l0, lp.weight_ih_l1, lp.weight_hh_l1,
                                                   lp.bias_ih_l1 + lp.bias_hh_l1, self.output_layer[0].weight,
                                                   self.output_layer[0].bias, self.output_layer[2].weight,
@@ -218,6 +221,7 @@ class Generator(nn.Module):
         tm = None
         if any(tf_mask):
             tm = torch.tensor([1 if b else 0 for b in tf_mask], dtype=torch.uint8).to(start.device)
+            tm.gmt_host_list = [bool(b) for b in tf_mask]
         return self._rollout(start, end, z, target_sequences.transpose(0, 1), tm, T, dropout_seed, padded=True)
 
     def forward(self, start, end, z, target_sequences: Optional[torch.Tensor] = None,
@@ -235,6 +239,7 @@ class Generator(nn.Module):
             tm = None
             if any(tf_mask):
                 tm = torch.tensor([1 if b else 0 for b in tf_mask], dtype=torch.uint8).to(start.device)
+                tm.gmt_host_list = [bool(b) for b in tf_mask]
             out = self._rollout(start, end, z, target_sequences.transpose(0, 1), tm, T, dropout_seed)
         else:
             T = self.config.max_generation_steps

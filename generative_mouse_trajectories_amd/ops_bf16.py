@@ -141,7 +141,12 @@ class CriticBodyBf16Fn(torch.autograd.Function):
         dev = pos.device
         M = L * B
         lengths = lengths.contiguous()
-        ragged = bool((lengths.min() < L).item())
+        # whether any row is shorter than L selects the kernel variant: a HOST decision.  Whoever made `lengths` may have
+        # left the answer on the tensor (Trainer._critic_inputs, from the batch's lengths before they went to the device:
+        # no synchronisation); otherwise it is read back here (one blocking device-to-host copy per call)
+        ragged = getattr(lengths, 'gmt_ragged', None)
+        if ragged is None:
+            ragged = bool((lengths.min() < L).item())
         need_grad = any(ctx.needs_input_grad)
         # kinematic features, zero-padded to one 64-wide K tile
         feat = torch.empty(L, B, 9, device=dev, dtype=torch.float32)

@@ -401,6 +401,7 @@ class Trainer:
         self.device = device
         self.use_amp = False          # fp32 parity configuration
         self._bf16 = getattr(config, 'compute_dtype', 'fp32') == 'bf16'
+        self._ragged_key = self._ragged_val = self._ragged_ref = None
         self.scaler = None
         self.world_size = world_size
         self.process_group = process_group
@@ -563,15 +564,26 @@ class Trainer:
             batch_size = sequences.shape[0]
             Bp = ops.pad_rows(batch_size, ops.row_tile(self.config))
             real_pos, real_dts = ops.traj_from_seq(sequences.float(), starts, False, batch_size, Bp)
-            lens_p1 = self._critic_inputs(lengths, Bp)
+            lens_p1 = self._critic_inputs(lengths, Bp, next_batch['lengths'], sequences.shape[1])
             real_score = D.forward_tm(real_pos, real_dts, lens_p1)[:batch_size]
         self._spec_real = {'batch': next_batch, 'd_version': self._d_version, 'training': D.training, 'stream': other,
                            'real_pos': real_pos, 'real_dts': real_dts, 'lens_p1': lens_p1, 'real_score': real_score}
 
-    def _critic_inputs(self, lengths: torch.Tensor, Bp: int) -> torch.Tensor:
+    def _critic_inputs(self, lengths: torch.Tensor, Bp: int, host_lengths: Optional[torch.Tensor] = None,
+                       T: Optional[int] = None) -> torch.Tensor:
         """lengths + 1 (positions incl. the start point, RG.py:957 / 960 / 1064) as the kernels' int32 [Bp]
-        (clamped to >= 1 like RG.py:766; padding rows have length 1)."""
-        return _pad_batch((lengths + 1).to(dtype=torch.int32).clamp(min=1), Bp, 0, 1).contiguous()
+        (clamped to >= 1 like RG.py:766; padding rows have length 1).  The bf16 critic picks its kernel variant by whether
+        any row is shorter than the batch's length: answered here from the batch's own lengths - on the host when the
+        batch came from a DataLoader, once per lengths tensor otherwise - and left on the result (`gmt_ragged`)."""
+        out = _pad_batch((lengths + 1).to(dtype=torch.int32).clamp(min=1), Bp, 0, 1).contiguous()
+        if self._bf16 and host_lengths is not None and T is not None:
+            key = (id(host_lengths), host_lengths._version, T, Bp)
+            if self._ragged_key != key:
+                short = bool((host_lengths.min() < T).item()) or Bp != host_lengths.numel()    # (padding rows have length 1)
+                self._ragged_key, self._ragged_val = key, short
+                self._ragged_ref = host_lengths              # keeps the id from being reused while cached
+            out.gmt_ragged = self._ragged_val
+        return out
 
     def train_discriminator_step(self, real_batch: Dict, noise: Optional[Dict] = None) -> Dict[str, float]:
         noise = noise or {}
@@ -605,7 +617,7 @@ class Trainer:
         with torch.no_grad():
             fake_tm = G.forward_tm(starts, ends, z, sequences, [False] * T)              # (T,Bp,3), RG.py:938-944
             fake_pos, fake_dts = ops.traj_from_seq(fake_tm, starts, True, batch_size, Bp)     # RG.py:946-949
-        lens_p1 = self._critic_inputs(lengths, Bp)
+        lens_p1 = self._critic_inputs(lengths, Bp, real_batch['lengths'], T)
         real_score = spec_r['real_score'] if spec_r is not None else D.forward_tm(real_pos, real_dts, lens_p1)[:batch_size]
         fake_score = D.forward_tm(fake_pos, fake_dts, lens_p1)[:batch_size]              # fake_lengths == lengths (RG.py:599-600)
         d_loss = fake_score.mean() - real_score.mean()
@@ -674,7 +686,7 @@ class Trainer:
         for p in d_params:
             p.requires_grad_(False)
         try:
-            fake_score = D.forward_tm(fake_pos, fake_dts, self._critic_inputs(lengths, Bp))[:batch_size]   # RG.py:1064
+            fake_score = D.forward_tm(fake_pos, fake_dts, self._critic_inputs(lengths, Bp, real_batch['lengths'], T))[:batch_size]   # RG.py:1064
         finally:
             for p in d_params:
                 p.requires_grad_(True)
