@@ -74,6 +74,10 @@ _SIGS = {
     'gmt_lstm_layer_fwd': [c_p] * 10 + [c_i] * 5 + [c_f, ctypes.c_uint, c_p],
     'gmt_lstm_layer_bwd': [c_p] * 11 + [c_i] * 4 + [c_f, ctypes.c_uint, c_p],
     'gmt_lstm_layer_bwd2': [c_p] * 12 + [c_i] * 5 + [c_p],
+    'gmt_lstm16_supported': [c_i, c_i],
+    'gmt_lstm16_layer_fwd': [c_p] * 7 + [c_i] * 4 + [c_p],
+    'gmt_lstm16_layer_bwd': [c_p] * 11 + [c_i] * 4 + [c_p],
+    'gmt_lstm16_layer_bwd2': [c_p] * 11 + [c_i] * 4 + [c_p],
     'gmt_lstm_xproj': [c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p],
     'gmt_wgrad_workspace_floats': [c_i, c_i, c_ll, c_p, c_p],
     'gmt_wgrad': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_ll, c_f, ctypes.c_uint, c_p],

@@ -395,6 +395,19 @@ def _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd, x_drop=(0.0, 0)):
 GP_HOIST_XPROJ = True
 
 
+# ... and with 16-row tiles (csrc/lstm_gp16.hip) whenever 32-row tiles would leave CUs empty: twice the workgroups
+GP_TILE16 = True
+
+
+def _gp16(H: int, B: int, nd: int) -> bool:
+    return (GP_TILE16 and GP_HOIST_XPROJ and (B // TM) * nd < 256 and bool(L_.lib().gmt_lstm16_supported(H, B)))
+
+
+def _hh_raw(w_hh) -> torch.Tensor:
+    """[nd, 4H, H]: the layer's recurrent weights as they are, stacked over directions (cached per optimizer step)."""
+    return derived('hh_raw', w_hh, lambda: torch.stack([w.detach() for w in w_hh]).contiguous())
+
+
 def lstm_xproj(x2: torch.Tensor, w_ih_pk: torch.Tensor, bias: Optional[torch.Tensor], nd: int, H: int, label: str) -> torch.Tensor:
     """x2 [R, I] -> [nd, R, 4H] = x W_ih^T (+ bias [nd, 4H]) in the gate buffers' unit-major column order."""
     R, I = x2.shape
@@ -423,10 +436,15 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         da = torch.empty_like(gates)
         dct = torch.empty(nd, L, B, H, device=dev, dtype=torch.float32)
         dht = torch.empty(nd, L, B, H, device=dev, dtype=torch.float32)
-        w_hh_pkT = derived('hh_pkT', w_hh, lambda: pack_transposed(w_hh, H, 4 * H))
-        L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
-                L_.ptr(dh_all), L_.ptr(dh_final), None, None, L_.ptr(da), L_.ptr(dct), L_.ptr(dht),
-                L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp', flops=2.0 * nd * L * B * 4 * H * H)
+        if _gp16(H, B, nd):
+            L_.call('gmt_lstm16_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(_hh_raw(w_hh)), L_.ptr(lengths),
+                    L_.ptr(dh_all), L_.ptr(dh_final), None, None, L_.ptr(da), L_.ptr(dct), L_.ptr(dht),
+                    L, B, H, nd, L_.stream(), label='lstm16_bwd_gp', flops=2.0 * nd * L * B * 4 * H * H)
+        else:
+            w_hh_pkT = derived('hh_pkT', w_hh, lambda: pack_transposed(w_hh, H, 4 * H))
+            L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
+                    L_.ptr(dh_all), L_.ptr(dh_final), None, None, L_.ptr(da), L_.ptr(dct), L_.ptr(dht),
+                    L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp', flops=2.0 * nd * L * B * 4 * H * H)
         dx = dx_from_da(da, w_ih, L * B)
         ctx.save_for_backward(gates, c_all, lengths, da, dct, dht, *w)
         ctx.dims = (L, B, I, H, nd)
@@ -446,7 +464,14 @@ class LSTMLayerBwdGPFn(torch.autograd.Function):
         g_c = torch.empty_like(c_all)
         w_ih_pk = derived('ih_pk', w_ih, lambda: pack_forward(w_ih, H, I))
         w_hh_pk = derived('hh_pk', w_hh, lambda: pack_forward(w_hh, H, H))
-        if GP_HOIST_XPROJ:
+        if _gp16(H, B, nd):
+            pre = lstm_xproj(xhat.view(L * B, I), w_ih_pk, None, nd, H, f'xproj_gp_I{I // H}')
+            L_.call('gmt_lstm16_layer_bwd2', L_.ptr(pre), L_.ptr(_hh_raw(w_hh)), L_.ptr(lengths),
+                    L_.ptr(gates), L_.ptr(c_all), L_.ptr(dct), L_.ptr(dht), L_.ptr(hhat_all), L_.ptr(hhat_final),
+                    L_.ptr(g_gates), L_.ptr(g_c), L, B, H, nd, L_.stream(), label='lstm16_bwd2',
+                    flops=2.0 * nd * L * B * 4 * H * H)
+            del pre
+        elif GP_HOIST_XPROJ:
             pre = lstm_xproj(xhat.view(L * B, I), w_ih_pk, None, nd, H, f'xproj_gp_I{I // H}')
             L_.call('gmt_lstm_layer_bwd2', L_.ptr(pre), None, L_.ptr(w_hh_pk), L_.ptr(lengths),
                     L_.ptr(gates), L_.ptr(c_all), L_.ptr(dct), L_.ptr(dht), L_.ptr(hhat_all), L_.ptr(hhat_final),
@@ -494,7 +519,13 @@ class LSTMLayerGPFn(torch.autograd.Function):
         h_final = torch.empty(B, nd * H, device=dev, dtype=torch.float32)
         w_ih_pk = derived('ih_pk', w_ih, lambda: pack_forward(w_ih, H, I))
         w_hh_pk = derived('hh_pk', w_hh, lambda: pack_forward(w_hh, H, H))
-        if GP_HOIST_XPROJ:
+        if _gp16(H, B, nd):
+            L_.call('gmt_lstm_xproj', L_.ptr(x), L_.ptr(w_ih_pk), L_.ptr(bias), L_.ptr(gates), L * B, I, H, nd, L_.stream(),
+                    label=f'xproj_gp_I{I // H}', flops=2.0 * nd * L * B * 4 * H * I)
+            L_.call('gmt_lstm16_layer_fwd', L_.ptr(gates), L_.ptr(_hh_raw(w_hh)), L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all),
+                    L_.ptr(h_all), L_.ptr(h_final), L, B, H, nd, L_.stream(), label='lstm16_fwd_gp',
+                    flops=2.0 * nd * L * B * 4 * H * H)
+        elif GP_HOIST_XPROJ:
             # x W_ih^T + b straight into the gate buffer (a full-machine launch); the persistent kernel reads its
             # step's slice from there a step ahead and overwrites it with the activated gates
             L_.call('gmt_lstm_xproj', L_.ptr(x), L_.ptr(w_ih_pk), L_.ptr(bias), L_.ptr(gates), L * B, I, H, nd, L_.stream(),
@@ -526,10 +557,15 @@ class LSTMLayerGPFn(torch.autograd.Function):
         cont = lambda t: None if t is None else t.contiguous()
         dh_all, dh_final, dgates, dc = cont(dh_all), cont(dh_final), cont(dgates), cont(dc)
         da = torch.empty_like(gates)
-        w_hh_pkT = derived('hh_pkT', w_hh, lambda: pack_transposed(w_hh, H, 4 * H))
-        L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
-                L_.ptr(dh_all), L_.ptr(dh_final), L_.ptr(dgates), L_.ptr(dc), L_.ptr(da), None, None,
-                L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp2', flops=2.0 * nd * L * B * 4 * H * H)
+        if _gp16(H, B, nd) and (dgates is None) == (dc is None):
+            L_.call('gmt_lstm16_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(_hh_raw(w_hh)), L_.ptr(lengths),
+                    L_.ptr(dh_all), L_.ptr(dh_final), L_.ptr(dgates), L_.ptr(dc), L_.ptr(da), None, None,
+                    L, B, H, nd, L_.stream(), label='lstm16_bwd_gp2', flops=2.0 * nd * L * B * 4 * H * H)
+        else:
+            w_hh_pkT = derived('hh_pkT', w_hh, lambda: pack_transposed(w_hh, H, 4 * H))
+            L_.call('gmt_lstm_layer_bwd', L_.ptr(gates), L_.ptr(c_all), L_.ptr(w_hh_pkT), L_.ptr(lengths),
+                    L_.ptr(dh_all), L_.ptr(dh_final), L_.ptr(dgates), L_.ptr(dc), L_.ptr(da), None, None,
+                    L, B, H, nd, 0.0, 0, L_.stream(), label='lstm_bwd_gp2', flops=2.0 * nd * L * B * 4 * H * H)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = dx_from_da(da, w_ih, L * B).view(L, B, I)

@@ -251,6 +251,24 @@ int gmt_lstm_layer_bwd2(const float* xhat, const float* w_ih_pk, const float* w_
                         float* hhat_all, float* hhat_final, float* g_gates, float* g_c,
                         int L, int B, int I, int H, int ndir, hipStream_t stream);
 
+/* 16-row-tile forms of the three sweeps above for the gradient-penalty pass (RG.py:790-842; H = 128, B % 16 == 0):
+ * a quarter of the batch fills a quarter of the CUs with 32-row tiles, these fill twice as many (csrc/lstm_gp16.hip).
+ * Hoisted inputs only: pregates / pre = the gmt_lstm_xproj result ([ndir][L][B][4H]; pregates may alias gates);
+ * w_hh [ndir][4H][H] = the layer's weight_hh parameters as they are (row-major, gate order i,f,g,o - no packing).
+ * _bwd is always out of place (da_out); dgates_extra / dc_extra and dct_out / dht_out are each given as a pair or not
+ * at all.  Same buffers, masks and results as gmt_lstm_layer_fwd / _bwd / _bwd2 (which remain the general forms). */
+int gmt_lstm16_supported(int H, int B);
+int gmt_lstm16_layer_fwd(const float* pregates, const float* w_hh, const int* lengths, float* gates, float* c_all,
+                         float* h_all, float* h_final, int L, int B, int H, int ndir, hipStream_t stream);
+int gmt_lstm16_layer_bwd(const float* gates, const float* c_all, const float* w_hh, const int* lengths,
+                         const float* dh_all, const float* dh_final, const float* dgates_extra, const float* dc_extra,
+                         float* da_out, float* dct_out, float* dht_out, int L, int B, int H, int ndir,
+                         hipStream_t stream);
+int gmt_lstm16_layer_bwd2(const float* pre, const float* w_hh, const int* lengths, const float* gates,
+                          const float* c_all, const float* dct_all, const float* dht_all, float* hhat_all,
+                          float* hhat_final, float* g_gates, float* g_c, int L, int B, int H, int ndir,
+                          hipStream_t stream);
+
 /* ---- weight-gradient contraction over time -------------------------------------------------
  * dW[n][i] (+)= sum_r dA[r][n] * X[r][i],  db[n] (+)= sum_r dA[r][n]  over R = L*B row-steps: the
  * dW_ih / dW_hh / db GEMMs autograd runs for RG.py:1021, 1109.  Split-K fp32-MFMA kernel with a

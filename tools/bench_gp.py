@@ -18,12 +18,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rows', type=int, default=1024)
     ap.add_argument('--no-hoist', action='store_true')
+    ap.add_argument('--no-tile16', action='store_true')
     ap.add_argument('--reps', type=int, default=6)
     args = ap.parse_args()
     import generative_mouse_trajectories_amd as gmt
     from generative_mouse_trajectories_amd import _lib, ops
     from generative_mouse_trajectories_amd.trainer import compute_gradient_penalty
     ops.GP_HOIST_XPROJ = not args.no_hoist
+    ops.GP_TILE16 = not args.no_tile16
     dev = torch.device('cuda:0')
     cfg = gmt.Config()
     cfg.latent_dim, cfg.generator_hidden_dim, cfg.discriminator_hidden_dim = 64, 128, 128
@@ -54,7 +56,7 @@ def main():
         one()
     e1.record()
     torch.cuda.synchronize()
-    print(f'gradient penalty pass, {b} rows, hoist={ops.GP_HOIST_XPROJ}: {e0.elapsed_time(e1) / args.reps:.2f} ms per pass; gp = {float(v):.6f}')
+    print(f'gradient penalty pass, {b} rows, hoist={ops.GP_HOIST_XPROJ} tile16={ops.GP_TILE16}: {e0.elapsed_time(e1) / args.reps:.2f} ms per pass; gp = {float(v):.6f}')
     _lib.profile_start()
     for _ in range(args.reps):
         one()
