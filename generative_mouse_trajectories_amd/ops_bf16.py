@@ -31,31 +31,42 @@ BF16 = torch.bfloat16
 # of its own, and a process has few hardware queues (GPU_MAX_HW_QUEUES = 4).  Round 2 met a run that never completed once
 # default-priority streams had filled them.  The default of two groups therefore only stands while
 # the process is known to hold few streams: as soon as a device-side process group (RCCL: communicator streams of its
-# own) is alive and nobody asked for a group count explicitly, layer calls run as ONE chain on the caller's stream.
+# own) is alive, layer calls run as ONE chain on the caller's stream, whatever count was asked for.
 # ----------------------------------------------------------------------------------------------------------------------
 import os as _os
 
-_ROW_GROUPS_EXPLICIT = 'GMT_BF16_ROW_GROUPS' in _os.environ
-_ROW_GROUPS_POLICY = None       # what apply_row_group_policy last decided (None: not called yet)
+_ROW_GROUPS_WANTED = None        # what set_row_groups was last asked for (None: the library's default / GMT_BF16_ROW_GROUPS)
+_ROW_GROUPS_POLICY = None        # what apply_row_group_policy last told the library (None: nothing yet)
 
 
-def set_row_groups(n: int) -> None:
-    """Explicit choice (1 or 2): overrides the policy below for the rest of the process."""
-    global _ROW_GROUPS_EXPLICIT
-    L_.call('gmt_bf16_set_row_groups', int(n))
-    _ROW_GROUPS_EXPLICIT = True
+def _device_group_alive() -> bool:
+    import torch.distributed as dist
+    return bool(dist.is_available() and dist.is_initialized() and dist.group.WORLD is not None
+                and 'nccl' in str(dist.get_backend(dist.group.WORLD)))
+
+
+def set_row_groups(n: int) -> int:
+    """Ask for n (1 or 2) row groups.  Returns what the library was told: 1 while a device-side process group is alive,
+    whatever was asked - round 3 ran exactly that combination (bf16 Trainer, one-rank RCCL group, overlap_g_forward, two
+    groups) at the end of the full GPU suite and the first D step never completed (profiles/r3_03_stream_count_stall_stacks.txt);
+    GMT_BF16_ROW_GROUPS_FORCE=1 lifts the guard for experiments."""
+    global _ROW_GROUPS_WANTED, _ROW_GROUPS_POLICY
+    _ROW_GROUPS_WANTED = int(n)
+    _ROW_GROUPS_POLICY = None
+    return apply_row_group_policy()
 
 
 def apply_row_group_policy() -> int:
-    """Called by the Trainer (construction and every bf16 step): one row group when a device-side process group is alive
-    and the count was not chosen explicitly, else the library's setting is left alone.  Returns the decision (0: left alone)."""
+    """Called by the Trainer before every bf16 step (and by set_row_groups): tells the library ONE row group while a
+    device-side process group (RCCL: communicator streams of its own) is alive, else the number asked for (default 2).
+    Returns the number in force."""
     global _ROW_GROUPS_POLICY
-    if _ROW_GROUPS_EXPLICIT:
-        return 0
-    import torch.distributed as dist
-    crowded = dist.is_available() and dist.is_initialized() and any(
-        'nccl' in str(dist.get_backend(g)) for g in ([dist.group.WORLD] if dist.group.WORLD is not None else []))
-    want = 1 if crowded else 2
+    want = _ROW_GROUPS_WANTED
+    if want is None:
+        want = int(_os.environ.get('GMT_BF16_ROW_GROUPS', '2'))
+    want = 1 if want < 1 else (2 if want > 2 else want)
+    if _device_group_alive() and not _os.environ.get('GMT_BF16_ROW_GROUPS_FORCE'):
+        want = 1
     if want != _ROW_GROUPS_POLICY:
         L_.call('gmt_bf16_set_row_groups', want)
         _ROW_GROUPS_POLICY = want

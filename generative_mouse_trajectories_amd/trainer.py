@@ -279,6 +279,21 @@ def dp_tf_coins(tf_seed: int, g_step: int, T: int, tf_ratio: float) -> List[bool
     return [bool(v) for v in (torch.rand(T, generator=g) < tf_ratio).tolist()]
 
 
+_SIDE_STREAMS: Dict = {}
+
+
+def side_stream(device: torch.device) -> 'torch.cuda.Stream':
+    """The ONE high-priority side stream of a device, shared by every Trainer of the process: a process has few hardware
+    queues (GPU_MAX_HW_QUEUES = 4) and every stream ever created keeps a share of one, so no Trainer makes its own."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        # high priority: once RCCL has created its own streams a default-priority side stream lands on the main stream's
+        # hardware queue and the two rollouts serialise (measured: +4 ms/step); priority streams come from a separate pool
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)
+    return st
+
+
 class StepMetrics(dict):
     """The dict of floats a step function returns (RG.py:1024-1029, 1112-1118) - same keys, same values - whose
     numbers are still on their way from the GPU when the function returns: the step's scalars are copied into
@@ -525,10 +540,7 @@ class Trainer:
         train_generator_step picks it up if nothing it depends on changed (same batch object, same G
         version, same teacher-forcing decisions, no injected z)."""
         if self._side is None:
-            # high priority: HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES = 4); once RCCL has
-            # created its own streams a default-priority side stream lands on the main stream's queue and the two
-            # rollouts serialise (measured: +4 ms/step); priority streams come from a separate pool
-            self._side = torch.cuda.Stream(device=self.device, priority=-1)
+            self._side = side_stream(self.device)
         main = torch.cuda.current_stream()
         self.generator.prepack()             # the cached weight packs are built on the main stream, both streams read them
         self._side.wait_stream(main)
@@ -555,7 +567,7 @@ class Trainer:
         power iterations on u / v as the reference (G step's critic call, then the D step's real call)."""
         cur = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device, priority=-1)
+            self._side = side_stream(self.device)
         other = self._main_stream if cur == self._side else self._side
         other.wait_event(before_bptt)
         D = self.discriminator

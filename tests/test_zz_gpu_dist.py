@@ -61,17 +61,21 @@ def test_overlapped_bucketed_allreduce_is_the_same_step(tmp_path):
 def test_bf16_trainer_with_rccl_group_overlap_and_two_row_groups_completes(tmp_path):
     """Round 2's stall was a stream COUNT (default stream + three default-priority library streams, then a two-stream
     sequence never completed).  The same count is within reach without a fourth row group: default
-    stream + the library's row-group stream + an RCCL communicator's streams + Trainer._side.  This is that combination:
-    bf16 Trainer (H = 512), one-rank RCCL group alive, overlap_g_forward on; first the library's policy (one row group
-    while a device-side process group is alive and nobody chose), then two row groups chosen explicitly - two iterations
-    each must complete (pytest's timeout is the verdict on a stall) with finite metrics."""
+    stream + the library's row-group stream + an RCCL communicator's streams + the Trainer's side stream.  Round 3 ran that
+    combination - bf16 Trainer (H = 512), one-rank RCCL group alive, overlap_g_forward on, TWO row groups - alone (completes)
+    and at the end of the full GPU suite: there the first D step with two groups never finished (the host parked in the
+    step's completion event, profiles/r3_03_stream_count_stall_stacks.txt), while the same step with one group completed
+    twice just before.  So the guard is not optional: while a device-side process group is alive the library is told ONE
+    row group whatever was asked for (ops_bf16.set_row_groups / apply_row_group_policy).  This test asks for two in exactly
+    that situation, checks that one is in force, and runs two iterations (pytest's timeout is the verdict on a stall)."""
     import generative_mouse_trajectories_amd as gmt
     from generative_mouse_trajectories_amd import ops_bf16
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(0)
     port = 27000 + os.getpid() % 4000
+    assert not os.environ.get('GMT_BF16_ROW_GROUPS_FORCE')
     dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=DEV)
-    was_explicit = ops_bf16._ROW_GROUPS_EXPLICIT
+    wanted = ops_bf16._ROW_GROUPS_WANTED
     try:
         cfg = gmt.Config()
         cfg.latent_dim, cfg.generator_hidden_dim, cfg.discriminator_hidden_dim = 16, 512, 512
@@ -89,23 +93,18 @@ def test_bf16_trainer_with_rccl_group_overlap_and_two_row_groups_completes(tmp_p
         batch = {'starts': starts.to(DEV), 'ends': (starts + deltas.sum(1)).to(DEV),
                  'sequences': torch.cat([deltas, torch.rand(B, T, 1, generator=g) + 0.2], -1).to(DEV),
                  'lengths': torch.full((B,), T, dtype=torch.long, device=DEV)}
-        ops_bf16._ROW_GROUPS_EXPLICIT = False
-        ops_bf16._ROW_GROUPS_POLICY = None
-        assert ops_bf16.apply_row_group_policy() == 1          # a device-side group is alive and nobody chose
-        for groups in (None, 2):
-            if groups is not None:
-                ops_bf16.set_row_groups(groups)                # explicit: the policy stands back
-                assert ops_bf16.apply_row_group_policy() == 0
-            for it in range(2):
-                md = dict(tr.train_discriminator_step(batch))
-                mg = dict(tr.train_generator_step(batch))
-                assert all(v == v and abs(v) < 1e6 for v in list(md.values()) + list(mg.values())), (groups, it, md, mg)
+        assert ops_bf16.set_row_groups(2) == 1                 # asked for two with a device-side group alive: one in force
+        for it in range(2):
+            md = dict(tr.train_discriminator_step(batch))
+            assert ops_bf16._ROW_GROUPS_POLICY == 1
+            mg = dict(tr.train_generator_step(batch, next_batch=batch))
+            assert all(v == v and abs(v) < 1e6 for v in list(md.values()) + list(mg.values())), (it, md, mg)
         torch.cuda.synchronize()
     finally:
-        ops_bf16._ROW_GROUPS_EXPLICIT = was_explicit
-        ops_bf16._ROW_GROUPS_POLICY = None
-        ops_bf16.L_.call('gmt_bf16_set_row_groups', 2)
         dist.destroy_process_group()
+        ops_bf16._ROW_GROUPS_WANTED = wanted
+        ops_bf16._ROW_GROUPS_POLICY = None
+        ops_bf16.apply_row_group_policy()                      # no group alive any more: back to the default
 
 
 def test_two_ranks_on_one_gpu_train_the_same_model_as_one_process(request, tmp_path):
