@@ -81,6 +81,7 @@ _SIGS = {
     'gmt_lstm_xproj': [c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p],
     'gmt_wgrad_workspace_floats': [c_i, c_i, c_ll, c_p, c_p],
     'gmt_wgrad': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_ll, c_f, ctypes.c_uint, c_p],
+    'gmt_wgrad_gates': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_ll, c_f, ctypes.c_uint, c_i, c_p],
     'gmt_wgrad_noalloc_init': [],
     'gmt_wgrad_noalloc': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_f, ctypes.c_uint, c_p],
     'gmt_encoder_fwd': [c_p] * 9 + [c_i, c_i, c_i, c_f, c_f, c_p],

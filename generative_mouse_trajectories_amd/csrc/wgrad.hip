@@ -215,9 +215,12 @@ void wgrad_kernel(const float* __restrict__ dA, long long lda, const float* __re
 // out[j] (+)= sum_k slab[k][j]; float4 lanes.  A block is 64 columns x 4 slab groups: group y sums
 // slabs [y*ksplit/4, (y+1)*ksplit/4) in order, then the four partial sums are added in order, so the
 // result is one fixed association of the additions (deterministic) with 4x the loads in flight.
+// perm_h > 0: the rows n of the result are in the gate buffers' UNIT-MAJOR order (n = 4 unit + gate, H = perm_h units)
+// and leave in torch's gate-major order (row gate H + unit), so that no separate permutation pass follows; I % 4 == 0
+// (whole float4 per row) or I == 1 (the bias gradient: one float4 = the four gates of one unit).
 __global__ __launch_bounds__(256)
 void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, long long n, int ksplit,
-                        int accumulate)
+                        int accumulate, int I, int perm_h)
 {
     __shared__ float4 part[4][64];
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
@@ -235,10 +238,22 @@ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
         part[y][x] = s;
         __syncthreads();
         if (y == 0 && i < n4) {
-            float4 t = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { t.x += part[q][x].x; t.y += part[q][x].y; t.z += part[q][x].z; t.w += part[q][x].w; }
-            reinterpret_cast<float4*>(out)[i] = t;
+            if (perm_h > 0 && I == 1) {                         // bias: elements 4 i .. 4 i + 3 are gates 0..3 of unit i
+                float* o = out + i;
+                if (accumulate) { t.x += o[0]; t.y += o[perm_h]; t.z += o[2 * (long long)perm_h]; t.w += o[3 * (long long)perm_h]; }
+                o[0] = t.x; o[perm_h] = t.y; o[2 * (long long)perm_h] = t.z; o[3 * (long long)perm_h] = t.w;
+            } else {
+                long long d = i;
+                if (perm_h > 0) {
+                    const long long row = (4 * i) / I, c4 = ((4 * i) % I) >> 2;
+                    d = (((row & 3) * perm_h + (row >> 2)) * (long long)I >> 2) + c4;
+                }
+                if (accumulate) { const float4 a = reinterpret_cast<const float4*>(out)[d]; t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
+                reinterpret_cast<float4*>(out)[d] = t;
+            }
         }
         __syncthreads();
     }
@@ -331,7 +346,16 @@ extern "C" int gmt_wgrad(const float* dA, long long lda, const float* X, long lo
                          float* dW, float* db, int accumulate, float* workspace, long long workspace_floats,
                          float x_dropout_p, unsigned x_dropout_seed, hipStream_t stream)
 {
+    return gmt_wgrad_gates(dA, lda, X, ldx, R, N, I, dW, db, accumulate, workspace, workspace_floats, x_dropout_p,
+                           x_dropout_seed, 0, stream);
+}
+
+extern "C" int gmt_wgrad_gates(const float* dA, long long lda, const float* X, long long ldx, long long R, int N, int I,
+                               float* dW, float* db, int accumulate, float* workspace, long long workspace_floats,
+                               float x_dropout_p, unsigned x_dropout_seed, int unit_major_h, hipStream_t stream)
+{
     GMT_CHECK_ARG(dA && X && dW && workspace);
+    GMT_CHECK_ARG(unit_major_h == 0 || (N == 4 * unit_major_h && (I % 4) == 0 && (((uintptr_t)dW) & 15) == 0));
     GMT_CHECK_ARG(x_dropout_p >= 0.f && x_dropout_p < 1.f);
     const int shape = wgrad_shape(N, I, ldx);
     GMT_CHECK_ARG(shape >= 0);
@@ -356,13 +380,14 @@ extern "C" int gmt_wgrad(const float* dA, long long lda, const float* X, long lo
     GMT_LAUNCH_CHECK();
     const long long n = (long long)N * I;
     if ((n % 4) == 0 && (((uintptr_t)dW) & 15) == 0)
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gmt_grid_1d(n / 4, 64)), dim3(256), 0, stream, slab, dW, n, ks, accumulate);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gmt_grid_1d(n / 4, 64)), dim3(256), 0, stream, slab, dW, n, ks, accumulate,
+                           I, unit_major_h);
     else
         hipLaunchKernelGGL(slab_reduce_scalar_kernel, dim3(gmt_grid_1d(n, 256)), dim3(256), 0, stream, slab, dW, n, ks, accumulate);
     GMT_LAUNCH_CHECK();
     if (db) {
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(gmt_grid_1d(N / 4, 64)), dim3(256), 0, stream, db_slab, db,
-                           (long long)N, ks, accumulate);
+                           (long long)N, ks, accumulate, 1, unit_major_h);
         GMT_LAUNCH_CHECK();
     }
     return GMT_OK;

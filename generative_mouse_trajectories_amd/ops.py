@@ -45,7 +45,13 @@ def gate_unperm(w: torch.Tensor) -> torch.Tensor:
 
 
 def wgrad_gates(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False, x_drop: Tuple[float, int] = (0.0, 0)):
-    """wgrad for a d(pre-activation) buffer (unit-major columns): results in torch's gate-major order."""
+    """wgrad for a d(pre-activation) buffer (unit-major columns): results in torch's gate-major order - straight from the
+    kernel's slab reduction when the shape allows (gmt_wgrad_gates), else by a permutation pass."""
+    N = dA.shape[1]
+    if N % 4 == 0 and X.shape[1] % 4 == 0:
+        out = wgrad(dA, X, want_db, x_drop, unit_major_h=N // 4)
+        if out is not None:
+            return out
     dW, db = wgrad(dA, X, want_db, x_drop)
     return gate_unperm(dW), (None if db is None else gate_unperm(db))
 
@@ -162,7 +168,8 @@ def pack_transposed(ws: List[torch.Tensor], n_out: int, K: int, col0: int = 0, n
 # ----------------------------------------------------------------------------------------
 # weight-gradient contraction over time (split-K MFMA kernel, csrc/wgrad.hip)
 # ----------------------------------------------------------------------------------------
-def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False, x_drop: Tuple[float, int] = (0.0, 0)):
+def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False, x_drop: Tuple[float, int] = (0.0, 0),
+          unit_major_h: int = 0):
     """dW = dA^T X over the rows (dA [R,N] contiguous, X [R,I] a row-strided view); optionally
     db = dA.sum(0).  Kernel shapes (csrc/wgrad.hip): N % 4 == 0 and either I % 128 == 0 with a
     16-byte aligned X, or a skinny X (I <= 32, any row pitch); R % 16 == 0.  Anything else goes
@@ -174,6 +181,8 @@ def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False, x_drop: Tupl
     ok = (dA.is_cuda and N % 4 == 0 and R % 16 == 0 and R >= 16 and dA.is_contiguous() and dA.data_ptr() % 16 == 0
           and X.stride(1) == 1 and (wide or I <= 32) and dA.dtype == torch.float32 and X.dtype == torch.float32)
     if not ok:
+        if unit_major_h:
+            return None                      # the caller permutes the fallback's result itself
         if x_drop[0] > 0:
             raise L_.GmtError('wgrad: the fused dropout mask needs the split-K kernel (I % 128 == 0, R % 16 == 0)')
         dW = torch.mm(dA.t(), X)
@@ -184,9 +193,9 @@ def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False, x_drop: Tupl
     ws = torch.empty(need.value, device=dA.device, dtype=torch.float32)
     dW = torch.empty(N, I, device=dA.device, dtype=torch.float32)
     db = torch.empty(N, device=dA.device, dtype=torch.float32) if want_db else None
-    L_.call('gmt_wgrad', dA.data_ptr(), N, X.data_ptr(), X.stride(0), R, N, I, dW.data_ptr(),
+    L_.call('gmt_wgrad_gates', dA.data_ptr(), N, X.data_ptr(), X.stride(0), R, N, I, dW.data_ptr(),
             None if db is None else db.data_ptr(), 0, ws.data_ptr(), need.value, float(x_drop[0]), int(x_drop[1]),
-            L_.stream(), label=f'wgrad_N{N}_I{I}', flops=2.0 * R * N * I)
+            int(unit_major_h), L_.stream(), label=f'wgrad_N{N}_I{I}', flops=2.0 * R * N * I)
     return dW, db
 
 

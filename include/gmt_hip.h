@@ -282,6 +282,13 @@ int gmt_wgrad(const float* dA, long long lda, const float* X, long long ldx, lon
               float* dW, float* db, int accumulate, float* workspace, long long workspace_floats,
               float x_dropout_p, unsigned x_dropout_seed, hipStream_t stream);
 
+/* gmt_wgrad_gates: gmt_wgrad for a dA that is a gate buffer (unit-major columns 4 u + g, N = 4 unit_major_h): dW / db leave
+ * in torch's gate-major row order (g H + u) straight from the slab reduction - no permutation pass afterwards.
+ * unit_major_h == 0 is gmt_wgrad.  I % 4 == 0. */
+int gmt_wgrad_gates(const float* dA, long long lda, const float* X, long long ldx, long long R, int N, int I,
+                    float* dW, float* db, int accumulate, float* workspace, long long workspace_floats,
+                    float x_dropout_p, unsigned x_dropout_seed, int unit_major_h, hipStream_t stream);
+
 /* gmt_wgrad_noalloc: gmt_wgrad for callers that cannot allocate - code under HIP graph capture, tight
  * serving / training loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference (which
  * never allocates device memory itself).  Same kernels and same results as gmt_wgrad bit for bit; the split-K

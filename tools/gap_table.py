@@ -53,7 +53,7 @@ for i, it in enumerate(its):
                 cur_end = e
                 last_name = n
     wall = (e1 - s0) * 1e-6
-    kind = 'gp' if any('lstm_bwd2_kernel' in r[2] for r in it) else 'plain'
+    kind = 'gp' if any('bwd2_kernel' in r[2] for r in it) else 'plain'
     bgap = (s0 - prev_end) * 1e-6 if prev_end is not None else 0.0
     prev_end = e1
     if i >= skip:
@@ -78,7 +78,7 @@ nk = {'gp': 0, 'plain': 0}
 for i, it in enumerate(its):
     if i < skip:
         continue
-    kind = 'gp' if any('lstm_bwd2_kernel' in r[2] for r in it) else 'plain'
+    kind = 'gp' if any('bwd2_kernel' in r[2] for r in it) else 'plain'
     nk[kind] += 1
     for s, e, n in it:
         per[kind][n][0] += (e - s) * 1e-6
