@@ -319,6 +319,8 @@ def main():
                     help='config 2 at one GPU only: skip the config 3 and config 5 measurements that follow the headline timed region')
     ap.add_argument('--no-overlap', action='store_true', help='run the two generator rollouts of an iteration one after the other')
     ap.add_argument('--cpu-threads', type=int, default=16)
+    ap.add_argument('--no-mlp-kernels', action='store_true',
+                    help='A/B: condition encoder and critic head as torch ops instead of csrc/mlp.hip')
     ap.add_argument('--no-real-overlap', action='store_true',
                     help='do not launch the next D step\'s real-sample critic forward beside the G step\'s BPTT kernel')
     ap.add_argument('--sync-metrics', action='store_true',
@@ -330,6 +332,9 @@ def main():
     if args.warmup is None:
         args.warmup = 8
 
+    if args.no_mlp_kernels:
+        from generative_mouse_trajectories_amd import ops as _ops
+        _ops.MLP_KERNELS = False
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -10,7 +10,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libgmt_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 ERRORS = {-1: 'bad argument (null pointer / shape / alignment)', -2: 'unsupported configuration',
@@ -59,6 +59,30 @@ class SnBwdLayer(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ('d_w_sn', 'w_orig', 'uv_saved', 'sigma', 'd_w_orig')] + [('out_features', c_i), ('in_features', c_i)]
 
 
+class CondFwdArgs(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in ('start', 'end', 'z')] + [(n, c_ll) for n in ('ld_start', 'ld_end', 'ld_z')] \
+        + [(n, c_p) for n in ('w1', 'b1', 'ln1_g', 'ln1_b', 'w2', 'b2', 'ln2_g', 'ln2_b', 'w_g')] + [('ld_wg', c_ll)] \
+        + [(n, c_p) for n in ('bias_a', 'bias_b', 'cond', 'g0', 'c_in', 'xhat1', 'rstd1', 'a1', 'xhat2', 'rstd2')] \
+        + [(n, c_i) for n in ('B', 'Bp', 'H', 'latent', 'c_pitch', 'g0_unit_major')] \
+        + [(n, c_f) for n in ('slope', 'ln_eps', 'dist_eps')]
+
+
+class CondBwdArgs(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in ('d_g0', 'd_cond', 'w_g')] + [('ld_wg', c_ll)] \
+        + [(n, c_p) for n in ('cond', 'xhat2', 'rstd2', 'ln2_g', 'w2', 'a1', 'xhat1', 'rstd1', 'ln1_g', 'dy2', 'dy1', 'ln_part')] \
+        + [(n, c_i) for n in ('B', 'Bp', 'H', 'g0_unit_major')] + [('slope', c_f)]
+
+
+class HeadFwdArgs(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in ('x', 'w1', 'b1', 'w2', 'b2', 'w3', 'b3', 'score', 'a1', 'a2')] \
+        + [(n, c_i) for n in ('Bp', 'H', 'a2_pitch')] + [('slope', c_f), ('dropout_p', c_f), ('seed', ctypes.c_uint)]
+
+
+class HeadBwdArgs(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in ('d_score', 'a1', 'a2', 'w1', 'w2', 'w3', 'dx', 'dy1', 'dy2', 'ds4')] \
+        + [(n, c_i) for n in ('Bp', 'H', 'a2_pitch')] + [('slope', c_f), ('dropout_p', c_f), ('seed', ctypes.c_uint)]
+
+
 SN_MAX_LAYERS = 8
 
 _SIGS = {
@@ -82,6 +106,11 @@ _SIGS = {
     'gmt_wgrad_workspace_floats': [c_i, c_i, c_ll, c_p, c_p],
     'gmt_wgrad': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_ll, c_f, ctypes.c_uint, c_p],
     'gmt_wgrad_gates': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_ll, c_f, ctypes.c_uint, c_i, c_p],
+    'gmt_slab_sum': [c_p, c_p, c_ll, c_i, c_i, c_p],
+    'gmt_cond_encoder_fwd': [c_p, c_p],
+    'gmt_cond_encoder_bwd': [c_p, c_p],
+    'gmt_critic_head_fwd': [c_p, c_p],
+    'gmt_critic_head_bwd': [c_p, c_p],
     'gmt_wgrad_noalloc_init': [],
     'gmt_wgrad_noalloc': [c_p, c_ll, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_f, ctypes.c_uint, c_p],
     'gmt_encoder_fwd': [c_p] * 9 + [c_i, c_i, c_i, c_f, c_f, c_p],

@@ -276,7 +276,9 @@ __global__ void slab_reduce_scalar_kernel(const float* __restrict__ slab, float*
 static int wgrad_shape(int N, int I, long long ldx)
 {
     if (N < 4 || (N % 4) != 0 || I < 1) return -1;
-    const bool wide = (I % 128) == 0 && (ldx % 4) == 0;
+    // wide tiles read whole 128-column blocks of X: I % 128 == 0, or 32 < I with rows padded (readable, finite) up to the
+    // next multiple of 128 - columns >= I of the edge tile are dropped at the store
+    const bool wide = (ldx % 4) == 0 && ((I % 128) == 0 || (I > 32 && ldx >= ((I + 127) / 128) * 128));
     if (!wide && I > 32) return -1;
     const bool big = (N % 256) == 0;                    // (128 x 128 tiles for N = 512 measured no faster)
     return wide ? (big ? 0 : 1) : (big ? 2 : 3);
@@ -284,7 +286,7 @@ static int wgrad_shape(int N, int I, long long ldx)
 
 extern "C" int gmt_wgrad_workspace_floats(int N, int I, long long R, int* ksplit_out, long long* floats_out)
 {
-    const int shape = wgrad_shape(N, I, 4);
+    const int shape = wgrad_shape(N, I, ((I + 127) / 128) * 128);   // (gmt_wgrad checks the real pitch)
     GMT_CHECK_ARG(shape >= 0 && R >= WG_RC && (R % WG_RC) == 0);
     const int TN = (shape == 0 || shape == 2) ? 256 : 128, TI = (shape <= 1) ? 128 : 32;
     const int tiles = ((N + TN - 1) / TN) * ((I + TI - 1) / TI);
@@ -318,6 +320,14 @@ int wgrad_scratch_ptr(float** out)
     return GMT_OK;
 }
 }  // namespace
+
+extern "C" int gmt_slab_sum(const float* slab, float* out, long long n, int k, int accumulate, hipStream_t stream)
+{
+    GMT_CHECK_ARG(slab && out && n >= 4 && (n % 4) == 0 && k >= 1 && ((((uintptr_t)slab) | ((uintptr_t)out)) & 15) == 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(gmt_grid_1d(n / 4, 64)), dim3(256), 0, stream, slab, out, n, k, accumulate, 4, 0);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
 
 extern "C" int gmt_wgrad_noalloc_init(void)
 {

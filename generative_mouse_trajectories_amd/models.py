@@ -148,15 +148,19 @@ class Generator(nn.Module):
         # (with a bf16 critic beside this fp32 rollout - compute_dtype 'bf16', H <= 256 here - the batch is padded to the
         # critic's 256-row tile, so that the step functions' time-major buffers all have one row count)
         Bp = ops.pad_rows(B, ops.row_tile(self.config))
-        cond = self._compute_condition(start, end, z)
         lp = self.lstm
         w_ih0 = lp.weight_ih_l0
-        g0 = F.linear(cond, w_ih0[:, 3:3 + H], lp.bias_ih_l0 + lp.bias_hh_l0)
+        if ops.cond_encoder_supported(self):
+            # condition features, both Linear / LayerNorm / LeakyReLU stages and the hoisted gate term in one launch, already
+            # padded to Bp rows and in the unit-major column order of the rollout's gate buffers (csrc/mlp.hip)
+            _, g0 = ops.cond_encoder(self, start, end, z, Bp, unit_major=True, want_g0=True)
+        else:                                            # widths outside the kernel's table (H not a power of two): torch ops
+            cond = self._compute_condition(start, end, z)
+            g0 = F.linear(cond, w_ih0[:, 3:3 + H], lp.bias_ih_l0 + lp.bias_hh_l0)
+            g0 = _pad_batch(g0, Bp, 0)
+            g0 = g0.view(Bp, 4, H).transpose(1, 2).reshape(Bp, 4 * H)
         w_u = torch.cat([w_ih0[:, :3], w_ih0[:, 3 + H:]], dim=1)
         bias1 = lp.bias_ih_l1 + lp.bias_hh_l1
-        g0 = _pad_batch(g0, Bp, 0)
-        # the rollout kernel reads it in the unit-major column order of its gate buffers (one float4 per row and unit)
-        g0 = g0.view(Bp, 4, H).transpose(1, 2).reshape(Bp, 4 * H)
         s_p, e_p = _pad_batch(start, Bp, 0), _pad_batch(end, Bp, 0)
         if target_tm is not None:
             target_tm = _pad_batch(target_tm, Bp, 1).contiguous()
@@ -182,18 +186,24 @@ class Generator(nn.Module):
         B = start.shape[0]
         H = self.config.generator_hidden_dim
         Bp = (B + ops_bf16.ROW_TILE - 1) // ops_bf16.ROW_TILE * ops_bf16.ROW_TILE
-        cond = _pad_batch(self._compute_condition(start, end, z), Bp, 0)
         lp = self.lstm
+        training_rollout = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        g0 = None
+        if ops.cond_encoder_supported(self):
+            cond, g0 = ops.cond_encoder(self, start, end, z, Bp, unit_major=False, want_g0=training_rollout)
+        else:
+            cond = _pad_batch(self._compute_condition(start, end, z), Bp, 0)
         if target_tm is not None:
             target_tm = _pad_batch(target_tm, Bp, 1).contiguous()
         p_drop = float(self.config.lstm_dropout) if self.training else 0.0
         if dropout_seed is None:
             dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
         drop = (p_drop, dropout_seed)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if training_rollout:
             # training rollout: every step's state is kept, BPTT in ops_bf16.GenRolloutBf16Fn
             w_ih0 = lp.weight_ih_l0
-            g0 = F.linear(cond, w_ih0[:, 3:3 + H], lp.bias_ih_l0 + lp.bias_hh_l0)
+            if g0 is None:
+                g0 = F.linear(cond, w_ih0[:, 3:3 + H], lp.bias_ih_l0 + lp.bias_hh_l0)
             w_u = torch.cat([w_ih0[:, :3], w_ih0[:, 3 + H:]], dim=1)
             # (the host's copy of the coins when the caller kept one - forward_tm / forward do: no device read-back)
             tf_list = getattr(tf_mask, 'gmt_host_list', None) if tf_mask is not None else None
@@ -342,7 +352,7 @@ class Discriminator(nn.Module):
             lw = [w for l in range(self.config.discriminator_num_layers) for w in self.lstm.layer_weights(l)]
             h_final = ops_bf16.critic_body(pos_tm, dts_tm, lengths_i32, slope, 1e-8, self.config.discriminator_num_layers,
                                            w1, fe[0].bias, w2, fe[2].bias, lw, (p, dropout_seed or 0))
-            return self.run_sequential(self.output_layers, h_final, sn_w)
+            return self.head(h_final, sn_w, dropout_seed)
         fused_enc = self.fuse_input_gemm and fe[3].negative_slope == fe[1].negative_slope
         if fused_enc:
             w1, w2 = sn_w.pop(0), sn_w.pop(0)
@@ -364,6 +374,22 @@ class Discriminator(nn.Module):
             x = h_all
             if l + 1 < nl and p > 0 and not fused:
                 x = F.dropout(x, p, True)
+        return self.head(h_final, sn_w, dropout_seed)
+
+    def head(self, h_final: torch.Tensor, sn_w: List[torch.Tensor], dropout_seed: Optional[int] = None) -> torch.Tensor:
+        """output_layers (RG.py:730-737) on the final hidden states [Bp, 2H] with the three normalised weights left in
+        `sn_w`: one launch (ops.CriticHeadFn) with the head's Dropout as a counter-based mask (seed derived from
+        `dropout_seed`, else drawn on the host), torch ops for widths outside the kernel's table."""
+        ol = self.output_layers
+        H = self.config.discriminator_hidden_dim
+        if (h_final.dtype == torch.float32 and ops.critic_head_supported(H) and h_final.shape[0] % ops.TM == 0
+                and ol[1].negative_slope == ol[4].negative_slope):
+            p = float(ol[2].p) if self.training else 0.0
+            seed = 0
+            if p > 0:
+                seed = dropout_seed + 7919 if dropout_seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            w1, w2, w3 = sn_w
+            return ops.critic_head(h_final, w1, ol[0].bias, w2, ol[3].bias, w3, ol[5].bias, float(ol[1].negative_slope), p, seed)
         return self.run_sequential(self.output_layers, h_final, sn_w)
 
     def forward(self, trajectories: torch.Tensor, dts: torch.Tensor, lengths: torch.Tensor,

@@ -169,15 +169,18 @@ def pack_transposed(ws: List[torch.Tensor], n_out: int, K: int, col0: int = 0, n
 # weight-gradient contraction over time (split-K MFMA kernel, csrc/wgrad.hip)
 # ----------------------------------------------------------------------------------------
 def wgrad(dA: torch.Tensor, X: torch.Tensor, want_db: bool = False, x_drop: Tuple[float, int] = (0.0, 0),
-          unit_major_h: int = 0):
+          unit_major_h: int = 0, x_padded: bool = False):
     """dW = dA^T X over the rows (dA [R,N] contiguous, X [R,I] a row-strided view); optionally
     db = dA.sum(0).  Kernel shapes (csrc/wgrad.hip): N % 4 == 0 and either I % 128 == 0 with a
     16-byte aligned X, or a skinny X (I <= 32, any row pitch); R % 16 == 0.  Anything else goes
     to rocBLAS.  x_drop = (p, seed): X is read through the fused inter-layer dropout mask
-    (counter r*ldx + i; wide X only - lstm_layer never asks for it otherwise)."""
+    (counter r*ldx + i; wide X only - lstm_layer never asks for it otherwise).
+    x_padded: the caller vouches that X is a column slice of a buffer whose rows are readable and ZERO up to the next
+    multiple of 128 columns (the saved activations of csrc/mlp.hip): 32 < I, I % 128 != 0 then runs on the wide tiles."""
     R, N = dA.shape
     I = X.shape[1]
-    wide = I % 128 == 0 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
+    wide = X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and \
+        (I % 128 == 0 or (x_padded and I > 32 and X.stride(0) >= (I + 127) // 128 * 128))
     ok = (dA.is_cuda and N % 4 == 0 and R % 16 == 0 and R >= 16 and dA.is_contiguous() and dA.data_ptr() % 16 == 0
           and X.stride(1) == 1 and (wide or I <= 32) and dA.dtype == torch.float32 and X.dtype == torch.float32)
     if not ok:
@@ -849,6 +852,193 @@ class GenAuxLossFn(torch.autograd.Function):
 
 def gen_aux_losses(seq_tm, starts, ends, lengths_i32):
     return GenAuxLossFn.apply(seq_tm, starts, ends, lengths_i32)
+
+
+# ----------------------------------------------------------------------------------------
+# the two small dense stacks (csrc/mlp.hip): generator condition encoder, critic output head
+# ----------------------------------------------------------------------------------------
+MLP_WIDTHS = (32, 64, 128, 256, 512)
+MLP_KERNELS = True       # False: condition encoder / critic head as torch ops (A/B switch, bench.py --no-mlp-kernels)
+
+
+def _pitch128(n: int) -> int:
+    """Row pitch of an activation that gmt_wgrad will read as X: n itself when the kernel takes it as it is
+    (n % 128 == 0 or skinny), else the next multiple of 128 (zero-filled padding, wgrad(x_padded=True))."""
+    return n if (n % 128 == 0 or n <= 32) else (n + 127) // 128 * 128
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+class CondEncoderFn(torch.autograd.Function):
+    """Generator._compute_condition + condition_encoder (RG.py:469-484, 440-447) and the hoisted gate term
+    g0 = cond . W_ih_l0[:, 3:3+H]^T + b_ih_l0 + b_hh_l0, one launch (gmt_cond_encoder_fwd); backward = one launch for the
+    data path (gmt_cond_encoder_bwd) + the weight-gradient contractions on gmt_wgrad.
+    (start [B,2], end [B,2], z [B,latent], w1, b1, ln1_g, ln1_b, w2, b2, ln2_g, ln2_b, w_ih0 [4H, 3+H+4], b_ih0, b_hh0,
+     Bp, unit_major, want_g0, slope, ln_eps) -> cond [Bp,H], g0 [Bp,4H] (empty tensor when want_g0 is False).
+    Rows >= B of both are zeros.  No gradient for start / end / z (network inputs in the reference's training loop)."""
+
+    @staticmethod
+    def forward(ctx, start, end, z, w1, b1, g1, be1, w2, b2, g2, be2, w_ih0, b_ih0, b_hh0, Bp, unit_major, want_g0,
+                slope, ln_eps):
+        L_.require_cuda(start, end, z, w1, w_ih0)
+        B, latent = z.shape
+        H = w2.shape[0]
+        assert w1.shape == (H, 6 + latent) and w_ih0.shape == (4 * H, 3 + H + 4) and Bp % TM == 0 and Bp >= B
+        dev = z.device
+        f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+        need = any(ctx.needs_input_grad[3:14])
+        start, end, z = _rows(start), _rows(end), _rows(z)
+        ws = [t.detach().contiguous() for t in (w1, b1, g1, be1, w2, b2, g2, be2, w_ih0, b_ih0, b_hh0)]
+        a = L_.CondFwdArgs()
+        a.start, a.end, a.z = start.data_ptr(), end.data_ptr(), z.data_ptr()
+        a.ld_start, a.ld_end, a.ld_z = start.stride(0), end.stride(0), z.stride(0)
+        (a.w1, a.b1, a.ln1_g, a.ln1_b, a.w2, a.b2, a.ln2_g, a.ln2_b) = [t.data_ptr() for t in ws[:8]]
+        cond = f(Bp, H)
+        g0 = f(Bp, 4 * H) if want_g0 else f(0)
+        a.cond = cond.data_ptr()
+        if want_g0:
+            a.w_g, a.ld_wg = ws[8].data_ptr() + 4 * 3, ws[8].shape[1]
+            a.bias_a, a.bias_b, a.g0 = ws[9].data_ptr(), ws[10].data_ptr(), g0.data_ptr()
+        saved = ()
+        cp = _pitch128(6 + latent)
+        if need:
+            saved = (f(Bp, cp), f(Bp, H), f(Bp), f(Bp, H), f(Bp, H), f(Bp))      # c_in, xhat1, rstd1, a1, xhat2, rstd2
+            a.c_in, a.xhat1, a.rstd1, a.a1, a.xhat2, a.rstd2 = [t.data_ptr() for t in saved]
+        a.B, a.Bp, a.H, a.latent, a.c_pitch, a.g0_unit_major = B, Bp, H, latent, cp, int(bool(unit_major))
+        a.slope, a.ln_eps, a.dist_eps = float(slope), float(ln_eps), 1e-8
+        L_.call('gmt_cond_encoder_fwd', ctypes_byref(a), L_.stream(), label='cond_encoder_fwd',
+                flops=2.0 * Bp * H * (6 + latent + H + (4 * H if want_g0 else 0)))
+        if need:
+            ctx.save_for_backward(cond, g1, w2, g2, w_ih0, *saved)
+            ctx.meta = (B, Bp, H, latent, cp, bool(unit_major), bool(want_g0), float(slope))
+        return cond, g0
+
+    @staticmethod
+    def backward(ctx, d_cond, d_g0):
+        if torch.is_grad_enabled():
+            raise NotImplementedError('CondEncoderFn: first-order backward only (the generator is never differentiated twice)')
+        cond, g1, w2, g2, w_ih0, c_in, xhat1, rstd1, a1, xhat2, rstd2 = ctx.saved_tensors
+        B, Bp, H, latent, cp, unit_major, want_g0, slope = ctx.meta
+        dev = cond.device
+        f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+        if not want_g0:
+            d_g0 = None
+        if d_g0 is not None:
+            d_g0 = d_g0.contiguous() if B == Bp else d_g0.clone(memory_format=torch.contiguous_format)   # pad rows are zeroed in place
+        if d_cond is not None:
+            d_cond = d_cond.contiguous()
+        if d_g0 is None and d_cond is None:
+            return (None,) * 19
+        w_ih0c, w2c = w_ih0.detach().contiguous(), w2.detach().contiguous()
+        g1c, g2c = g1.detach().contiguous(), g2.detach().contiguous()
+        dy2, dy1, ln_part = f(Bp, H), f(Bp, H), f(Bp // TM, 4, H)
+        a = L_.CondBwdArgs()
+        a.d_g0, a.d_cond = L_.ptr(d_g0), L_.ptr(d_cond)
+        a.w_g, a.ld_wg = w_ih0c.data_ptr() + 4 * 3, w_ih0c.shape[1]
+        a.cond, a.xhat2, a.rstd2, a.ln2_g = cond.data_ptr(), xhat2.data_ptr(), rstd2.data_ptr(), g2c.data_ptr()
+        a.w2, a.a1, a.xhat1, a.rstd1, a.ln1_g = w2c.data_ptr(), a1.data_ptr(), xhat1.data_ptr(), rstd1.data_ptr(), g1c.data_ptr()
+        a.dy2, a.dy1, a.ln_part = dy2.data_ptr(), dy1.data_ptr(), ln_part.data_ptr()
+        a.B, a.Bp, a.H, a.g0_unit_major, a.slope = B, Bp, H, int(unit_major), slope
+        L_.call('gmt_cond_encoder_bwd', ctypes_byref(a), L_.stream(), label='cond_encoder_bwd',
+                flops=2.0 * Bp * H * (H + (4 * H if d_g0 is not None else 0)))
+        d_w_ih0 = d_bg = None
+        if d_g0 is not None:
+            d_wg, d_bg = wgrad_gates(d_g0, cond, want_db=True) if unit_major else wgrad(d_g0, cond, want_db=True)
+            d_w_ih0 = F.pad(d_wg, (3, 4))                   # the condition columns of W_ih_l0 [4H, 3 + H + 4]
+        d_w2, d_b2 = wgrad(dy2, a1, want_db=True)
+        d_w1, d_b1 = wgrad(dy1, c_in[:, :6 + latent], want_db=True, x_padded=True)
+        ln = f(4, H)
+        L_.call('gmt_slab_sum', ln_part.data_ptr(), ln.data_ptr(), 4 * H, Bp // TM, 0, L_.stream(), label='skip')
+        return (None, None, None, d_w1, d_b1, ln[2], ln[3], d_w2, d_b2, ln[0], ln[1], d_w_ih0, d_bg, d_bg,
+                None, None, None, None, None)
+
+
+def cond_encoder_supported(G) -> bool:
+    ce = G.condition_encoder
+    return (MLP_KERNELS and G.config.generator_hidden_dim in MLP_WIDTHS and ce[2].negative_slope == ce[5].negative_slope
+            and ce[1].eps == ce[4].eps and ce[0].weight.dtype == torch.float32)
+
+
+def cond_encoder(G, start, end, z, Bp: int, unit_major: bool, want_g0: bool):
+    """cond [Bp,H] (+ g0 [Bp,4H]) of Generator `G` for the batch (start, end, z): see CondEncoderFn."""
+    ce, lp = G.condition_encoder, G.lstm
+    cond, g0 = CondEncoderFn.apply(start, end, z, ce[0].weight, ce[0].bias, ce[1].weight, ce[1].bias, ce[3].weight, ce[3].bias,
+                                   ce[4].weight, ce[4].bias, lp.weight_ih_l0, lp.bias_ih_l0, lp.bias_hh_l0, Bp, unit_major,
+                                   want_g0, float(ce[2].negative_slope), float(ce[1].eps))
+    return cond, (g0 if want_g0 else None)
+
+
+class CriticHeadFn(torch.autograd.Function):
+    """Discriminator.output_layers (RG.py:730-737 at RG.py:781) on the final hidden states, one launch each way
+    (gmt_critic_head_fwd / _bwd) + the weight-gradient contractions on gmt_wgrad.
+    (x [Bp,2H], w1 [H,2H], b1, w2 [H/2,H], b2, w3 [1,H/2], b3, slope, p, seed) -> score [Bp,1]; w1..w3 are the spectrally
+    normalised weights.  Dropout(p) is the counter-based mask gmt_keep(row * H + column, seed): dropout_keep_mask(1, Bp, H,
+    p, seed) is its host replica.  First-order backward only (the penalty pass keeps the torch composite)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, slope, p, seed):
+        L_.require_cuda(x, w1)
+        Bp, H2 = x.shape
+        H, N2 = H2 // 2, H2 // 4
+        assert Bp % TM == 0 and w1.shape == (H, H2) and w2.shape == (N2, H) and w3.shape == (1, N2)
+        dev = x.device
+        f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+        need = any(ctx.needs_input_grad[:7])
+        xc = x.detach().contiguous()
+        ws = [t.detach().contiguous() for t in (w1, b1, w2, b2, w3, b3)]
+        a2p = _pitch128(N2)
+        score = f(Bp, 1)
+        a = L_.HeadFwdArgs()
+        a.x = xc.data_ptr()
+        a.w1, a.b1, a.w2, a.b2, a.w3, a.b3 = [t.data_ptr() for t in ws]
+        a.score = score.data_ptr()
+        if need:
+            a1, a2 = f(Bp, H), f(Bp, a2p)
+            a.a1, a.a2 = a1.data_ptr(), a2.data_ptr()
+        a.Bp, a.H, a.a2_pitch = Bp, H, a2p
+        a.slope, a.dropout_p, a.seed = float(slope), float(p), int(seed) & 0xFFFFFFFF
+        L_.call('gmt_critic_head_fwd', ctypes_byref(a), L_.stream(), label='critic_head_fwd',
+                flops=2.0 * Bp * (H2 * H + H * N2 + N2))
+        if need:
+            ctx.save_for_backward(xc, w1, w2, w3, a1, a2)
+            ctx.meta = (Bp, H, a2p, float(slope), float(p), int(seed) & 0xFFFFFFFF)
+        return score
+
+    @staticmethod
+    def backward(ctx, d_score):
+        if torch.is_grad_enabled():
+            raise NotImplementedError('CriticHeadFn: first-order backward only (composite.discriminator_forward_gp is the '
+                                      'twice-differentiable critic)')
+        x, w1, w2, w3, a1, a2 = ctx.saved_tensors
+        Bp, H, a2p, slope, p, seed = ctx.meta
+        N2 = H // 2
+        dev = x.device
+        f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+        ds = d_score.contiguous()
+        w1c, w2c, w3c = w1.detach().contiguous(), w2.detach().contiguous(), w3.detach().contiguous()
+        dx, dy1, dy2, ds4 = f(Bp, 2 * H), f(Bp, H), f(Bp, N2), f(Bp, 4)
+        a = L_.HeadBwdArgs()
+        a.d_score, a.a1, a.a2 = ds.data_ptr(), a1.data_ptr(), a2.data_ptr()
+        a.w1, a.w2, a.w3 = w1c.data_ptr(), w2c.data_ptr(), w3c.data_ptr()
+        a.dx, a.dy1, a.dy2, a.ds4 = dx.data_ptr(), dy1.data_ptr(), dy2.data_ptr(), ds4.data_ptr()
+        a.Bp, a.H, a.a2_pitch, a.slope, a.dropout_p, a.seed = Bp, H, a2p, slope, p, seed
+        L_.call('gmt_critic_head_bwd', ctypes_byref(a), L_.stream(), label='critic_head_bwd',
+                flops=2.0 * Bp * (2 * H * H + H * N2 + N2))
+        d_w1, d_b1 = wgrad(dy1, x, want_db=True)
+        d_w2, d_b2 = wgrad(dy2, a1, want_db=True)
+        d_w3, d_b3 = wgrad(ds4, a2[:, :N2], want_db=True, x_padded=a2p != N2)
+        return dx, d_w1, d_b1, d_w2, d_b2, d_w3[:1], d_b3[:1], None, None, None
+
+
+def critic_head_supported(H: int) -> bool:
+    return MLP_KERNELS and H in MLP_WIDTHS
+
+
+def critic_head(x, w1, b1, w2, b2, w3, b3, slope: float = 0.2, p: float = 0.0, seed: int = 0):
+    return CriticHeadFn.apply(x, w1, b1, w2, b2, w3, b3, slope, p, seed)
 
 
 # ----------------------------------------------------------------------------------------

@@ -41,7 +41,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define GMT_ERR_WORKSPACE (-4)    /* caller's workspace is too small                     */
 
 /* ABI version of this header; gmt_version() of the loaded library must match. */
-#define GMT_ABI_VERSION 8
+#define GMT_ABI_VERSION 9
 int gmt_version(void);
 
 /* ---- kinematic features, "mode A" ---------------------------------------------------
@@ -305,6 +305,84 @@ int gmt_wgrad_noalloc_init(void);
 int gmt_wgrad_noalloc(const float* dA, long long lda, const float* X, long long ldx, long long R, int N, int I,
                       float* dW, float* db, int accumulate, float x_dropout_p, unsigned x_dropout_seed,
                       hipStream_t stream);
+
+/* gmt_slab_sum: out[j] (+)= sum_k slab[k][j], j < n (n % 4 == 0, 16-byte aligned), in one fixed order - the second pass of
+ * every split reduction here (gmt_wgrad's slabs, the per-tile LayerNorm parameter gradients of gmt_cond_encoder_bwd). */
+int gmt_slab_sum(const float* slab, float* out, long long n, int k, int accumulate, hipStream_t stream);
+
+/* ---- the two small dense stacks: generator condition encoder, critic output head -------------------------------
+ * One launch per direction each; a workgroup owns 32 rows (trajectories) and all columns, every activation of the
+ * stack stays in LDS between layers, weights are read row-major as they are (no packing).  H = 32 NW, NW in {1,2,4,8,16}.
+ *
+ * gmt_cond_encoder_fwd = Generator._compute_condition RG.py:469-484 (start, end, ||end - start|| = sqrt(. + 1e-8),
+ * atan2(dy, dx), z -> [B, 6 + latent]) + Generator.condition_encoder RG.py:440-447 (Linear, LayerNorm, LeakyReLU(0.2),
+ * Linear, LayerNorm, LeakyReLU(0.2)) + the time-invariant part of the layer-0 gate pre-activations that the rollout
+ * hoists out of its loop, g0 = cond . W_ih_l0[:, 3:3+H]^T + b_ih_l0 + b_hh_l0 (the `condition` columns of the LSTM
+ * input assembled at RG.py:566-569, applied by nn.LSTM at RG.py:571).  Rows >= B (batch padding up to Bp, Bp % 32 == 0)
+ * leave as zeros in every output. */
+typedef struct gmt_cond_fwd_args {
+    const float* start; const float* end; const float* z;      /* [B][2], [B][2], [B][latent] */
+    long long ld_start, ld_end, ld_z;                           /* row pitches (floats) */
+    const float* w1; const float* b1; const float* ln1_g; const float* ln1_b;   /* [H][6+latent], [H], [H], [H] */
+    const float* w2; const float* b2; const float* ln2_g; const float* ln2_b;   /* [H][H], [H], [H], [H] */
+    const float* w_g; long long ld_wg;     /* W_ih_l0 + 3 (first condition column), row pitch 3 + H + 4; NULL: no g0 */
+    const float* bias_a; const float* bias_b;                   /* b_ih_l0, b_hh_l0 [4H] */
+    float* cond;            /* [Bp][H]  out */
+    float* g0;              /* [Bp][4H] out (w_g given) */
+    /* saved for gmt_cond_encoder_bwd: all given (training) or all NULL */
+    float* c_in;            /* [Bp][c_pitch]: the 6 + latent inputs of the first Linear, zero-padded to the pitch */
+    float* xhat1; float* rstd1; float* a1;                      /* [Bp][H], [Bp], [Bp][H] */
+    float* xhat2; float* rstd2;                                 /* [Bp][H], [Bp] */
+    int B, Bp, H, latent, c_pitch;
+    int g0_unit_major;      /* 1: g0 columns 4 u + g (the fp32 rollout's gate buffers), 0: torch's g H + u */
+    float slope, ln_eps, dist_eps;
+} gmt_cond_fwd_args;
+int gmt_cond_encoder_fwd(const gmt_cond_fwd_args* args, hipStream_t stream);
+
+/* Backward of the same (autograd over RG.py:469-484 / 440-447 in the reference): the data path only - the adjoints of
+ * the two Linear pre-activations (dy2, dy1) and per-tile partial LayerNorm parameter gradients; the caller contracts
+ * d_g0 / dy2 / dy1 with cond / a1 / c_in on gmt_wgrad and sums ln_part with gmt_slab_sum.  d_g0 rows >= B are
+ * zeroed IN PLACE (so that the caller's weight-gradient contraction may run over all Bp rows). */
+typedef struct gmt_cond_bwd_args {
+    float* d_g0;            /* [Bp][4H] gradient of g0, or NULL */
+    const float* d_cond;    /* [Bp][H] gradient of cond, or NULL */
+    const float* w_g; long long ld_wg;
+    const float* cond; const float* xhat2; const float* rstd2; const float* ln2_g;
+    const float* w2; const float* a1; const float* xhat1; const float* rstd1; const float* ln1_g;
+    float* dy2; float* dy1; /* [Bp][H] out */
+    float* ln_part;         /* [Bp/32][4][H] out: per tile d ln2_g, d ln2_b, d ln1_g, d ln1_b */
+    int B, Bp, H, g0_unit_major;
+    float slope;
+} gmt_cond_bwd_args;
+int gmt_cond_encoder_bwd(const gmt_cond_bwd_args* args, hipStream_t stream);
+
+/* gmt_critic_head_fwd = Discriminator.output_layers RG.py:730-737 applied at RG.py:781: Linear(2H -> H), LeakyReLU(0.2),
+ * Dropout(p), Linear(H -> H/2), LeakyReLU(0.2), Linear(H/2 -> 1) on the final hidden states; the weights are the
+ * spectrally normalised ones (gmt_spectral_norm_fwd).  Dropout is a counter-based mask (gmt_keep of element
+ * row * H + column, lstm_tile.h): backward regenerates it, nothing is stored; p = 0 in eval mode. */
+typedef struct gmt_head_fwd_args {
+    const float* x;         /* [Bp][2H] */
+    const float* w1; const float* b1; const float* w2; const float* b2; const float* w3; const float* b3;
+    float* score;           /* [Bp] out */
+    float* a1;              /* [Bp][H] out: first activation after dropout (saved), or NULL */
+    float* a2;              /* [Bp][a2_pitch] out: second activation, zero-padded to the pitch (saved), or NULL */
+    int Bp, H, a2_pitch;
+    float slope, dropout_p; unsigned int seed;
+} gmt_head_fwd_args;
+int gmt_critic_head_fwd(const gmt_head_fwd_args* args, hipStream_t stream);
+
+/* Backward (autograd over RG.py:781): dx and the adjoints of the three Linear pre-activations, which the caller
+ * contracts with x / a1 / a2 on gmt_wgrad (ds4 = d_score padded to 4 columns for that kernel's N % 4 rule). */
+typedef struct gmt_head_bwd_args {
+    const float* d_score;   /* [Bp] */
+    const float* a1; const float* a2;
+    const float* w1; const float* w2; const float* w3;
+    float* dx;              /* [Bp][2H] out */
+    float* dy1; float* dy2; float* ds4;   /* [Bp][H], [Bp][H/2], [Bp][4] out */
+    int Bp, H, a2_pitch;
+    float slope, dropout_p; unsigned int seed;
+} gmt_head_bwd_args;
+int gmt_critic_head_bwd(const gmt_head_bwd_args* args, hipStream_t stream);
 
 /* ---- persistent generator rollout -----------------------------------------------------------
  * Replaces the autoregressive loop of Generator.forward, RG.py:508-604 (dynamic features

@@ -1,0 +1,163 @@
+"""GPU parity of the two small dense stacks (csrc/mlp.hip) against the same arithmetic in float64 torch ops on the CPU:
+the generator's condition encoder (RG.py:469-484, 440-447, plus the hoisted g0 term) and the critic's output head
+(RG.py:730-737).  The train-step tests of test_gpu_parity.py cover them end to end against the oracle and the reference's
+golden vectors; here every output and every gradient is checked on its own, on ragged batches and at several widths.
+Tolerance: fp32 contraction order only (1e-5 of the tensor's max-norm forward, 5e-5 on gradients)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def close(a, b, tol, what):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, f'{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}'
+    scale = max(float(b.abs().max()), 1e-6)
+    err = float((a - b).abs().max()) / scale
+    assert err <= tol, f'{what}: rel max err {err:.3e} > {tol:.1e}'
+
+
+def make_generator(H, latent, seed):
+    import generative_mouse_trajectories_amd as gmt
+    cfg = gmt.Config()
+    cfg.generator_hidden_dim, cfg.latent_dim = H, latent
+    cfg.lstm_dropout = 0.0
+    torch.manual_seed(seed)
+    G = gmt.Generator(cfg)
+    with torch.no_grad():                                   # LayerNorm parameters away from their (1, 0) initialisation
+        for m in G.condition_encoder:
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.add_(0.3 * torch.randn_like(m.weight))
+                m.bias.add_(0.2 * torch.randn_like(m.bias))
+    return gmt, cfg, G
+
+
+def cond_reference(G64, start, end, z, H):
+    """float64 torch ops on the CPU: the module's own _compute_condition + the F.linear the rollout used to take."""
+    lp = G64.lstm
+    cond = G64._compute_condition(start, end, z)
+    g0 = F.linear(cond, lp.weight_ih_l0[:, 3:3 + H], lp.bias_ih_l0 + lp.bias_hh_l0)
+    return cond, g0
+
+
+@pytest.mark.parametrize('H,latent,B,unit_major', [(128, 64, 96, True), (128, 64, 50, True), (32, 8, 7, False),
+                                                   (64, 64, 33, True), (256, 64, 40, True), (512, 64, 40, False)])
+def test_condition_encoder_forward_backward_vs_float64(H, latent, B, unit_major):
+    import copy
+    from generative_mouse_trajectories_amd import ops
+    gmt, cfg, G = make_generator(H, latent, 3) if H <= 256 else (None, None, None)
+    if G is None:                                           # H = 512 is the bf16 generator's width: same encoder modules
+        import generative_mouse_trajectories_amd as gmt
+        cfg = gmt.Config()
+        cfg.generator_hidden_dim, cfg.latent_dim, cfg.compute_dtype = H, latent, 'bf16'
+        cfg.discriminator_hidden_dim = 512
+        torch.manual_seed(3)
+        G = gmt.Generator(cfg)
+    G64 = copy.deepcopy(G).double()
+    G = G.to(DEV)
+    assert ops.cond_encoder_supported(G)
+    gen = torch.Generator().manual_seed(5)
+    start = torch.rand(B, 2, generator=gen)
+    end = torch.rand(B, 2, generator=gen)
+    z = torch.randn(B, latent, generator=gen)
+    Bp = ops.pad_rows(B)
+    cond, g0 = ops.cond_encoder(G, start.to(DEV), end.to(DEV), z.to(DEV), Bp, unit_major=unit_major, want_g0=True)
+    rc, rg0 = cond_reference(G64, start.double(), end.double(), z.double(), H)
+    assert cond.shape == (Bp, H) and g0.shape == (Bp, 4 * H)
+    g0_gate_major = g0.view(Bp, H, 4).transpose(1, 2).reshape(Bp, 4 * H) if unit_major else g0
+    close(cond[:B], rc, 1e-5, 'cond')
+    close(g0_gate_major[:B], rg0, 1e-5, 'g0')
+    assert float(cond[B:].abs().sum()) == 0.0 and float(g0[B:].abs().sum()) == 0.0, 'padding rows must be zeros'
+
+    # backward: random adjoints for both outputs; padding rows carry garbage that must not reach any gradient
+    wg = torch.randn(Bp, 4 * H, generator=gen)
+    wc = torch.randn(Bp, H, generator=gen)
+    ((g0_gate_major * wg.to(DEV)).sum() + (cond * wc.to(DEV)).sum()).backward()
+    ((rg0 * wg[:B].double()).sum() + (rc * wc[:B].double()).sum()).backward()
+    for (k, p), (_, q) in zip(G.named_parameters(), G64.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+            continue
+        close(p.grad, q.grad, 5e-5, f'grad {k}')
+
+
+def test_condition_encoder_unsupported_width_uses_torch_ops():
+    from generative_mouse_trajectories_amd import ops
+    gmt, cfg, G = make_generator(96, 64, 1)
+    assert not ops.cond_encoder_supported(G)
+
+
+def head_reference(x, w1, b1, w2, b2, w3, b3, slope, mask):
+    y = F.leaky_relu(F.linear(x, w1, b1), slope)
+    if mask is not None:
+        y = y * mask
+    y = F.leaky_relu(F.linear(y, w2, b2), slope)
+    return F.linear(y, w3, b3)
+
+
+@pytest.mark.parametrize('H,Bp,p', [(128, 64, 0.0), (128, 8192, 0.3), (32, 32, 0.3), (64, 96, 0.0), (256, 64, 0.3),
+                                    (512, 64, 0.3)])
+def test_critic_head_forward_backward_vs_float64(H, Bp, p):
+    from generative_mouse_trajectories_amd import ops
+    gen = torch.Generator().manual_seed(11 + H)
+    N2 = H // 2
+    x = torch.randn(Bp, 2 * H, generator=gen)
+    ws = [torch.randn(H, 2 * H, generator=gen) / (2 * H) ** 0.5, 0.1 * torch.randn(H, generator=gen),
+          torch.randn(N2, H, generator=gen) / H ** 0.5, 0.1 * torch.randn(N2, generator=gen),
+          torch.randn(1, N2, generator=gen) / N2 ** 0.5, 0.1 * torch.randn(1, generator=gen)]
+    seed = 4242
+    mask = ops.dropout_keep_mask(1, Bp, H, p, seed).view(Bp, H).double() if p > 0 else None
+    xd = x.to(DEV).requires_grad_(True)
+    wd = [w.to(DEV).requires_grad_(True) for w in ws]
+    score = ops.critic_head(xd, *wd, 0.2, p, seed)
+    x64 = x.double().requires_grad_(True)
+    w64 = [w.double().requires_grad_(True) for w in ws]
+    ref = head_reference(x64, *w64, 0.2, mask)
+    assert score.shape == (Bp, 1)
+    close(score, ref, 1e-5, 'score')
+    wgt = torch.randn(Bp, 1, generator=gen)
+    (score * wgt.to(DEV)).sum().backward()
+    (ref * wgt.double()).sum().backward()
+    close(xd.grad, x64.grad, 5e-5, 'dx')
+    for k, (a, b) in enumerate(zip(wd, w64)):
+        close(a.grad, b.grad, 5e-5, f'grad of head tensor {k}')
+    if p > 0:
+        kept = float((mask > 0).double().mean())
+        assert abs(kept - (1 - p)) < 0.05, f'kept fraction {kept}'
+
+
+def test_discriminator_uses_the_head_kernel_and_matches_its_torch_composite():
+    """Discriminator.forward through the kernel head vs the same module with the head forced onto torch ops
+    (head dropout off: the two masks are different generators)."""
+    import generative_mouse_trajectories_amd as gmt
+    from generative_mouse_trajectories_amd import _lib as L_
+    cfg = gmt.Config()
+    cfg.discriminator_hidden_dim = 128
+    cfg.lstm_dropout = cfg.head_dropout = 0.0
+    torch.manual_seed(2)
+    D = gmt.Discriminator(cfg).to(DEV).train()
+    gen = torch.Generator().manual_seed(9)
+    B, Lq = 40, 12
+    traj = torch.rand(B, Lq, 2, generator=gen).to(DEV)
+    dts = (0.01 + 0.02 * torch.rand(B, Lq, generator=gen)).to(DEV)
+    lengths = torch.randint(2, Lq + 1, (B,), generator=gen)
+    sd = {k: v.clone() for k, v in D.state_dict().items()}
+    L_.profile_start()
+    s1 = D(traj, dts, lengths)
+    s1.sum().backward()
+    torch.cuda.synchronize()
+    prof = L_.profile_stop()
+    assert 'critic_head_fwd' in prof and 'critic_head_bwd' in prof, sorted(prof)
+    g1 = {k: p.grad.clone() for k, p in D.named_parameters()}
+    D.load_state_dict(sd)                                   # rewind the spectral-norm power iteration
+    D.zero_grad()
+    D.head = lambda h, w, seed=None: D.run_sequential(D.output_layers, h, w)
+    s2 = D(traj, dts, lengths)
+    s2.sum().backward()
+    close(s1, s2, 2e-5, 'score')
+    for k, p in D.named_parameters():
+        close(g1[k], p.grad, 1e-4, f'grad {k}')
