@@ -319,6 +319,8 @@ def main():
                     help='config 2 at one GPU only: skip the config 3 and config 5 measurements that follow the headline timed region')
     ap.add_argument('--no-overlap', action='store_true', help='run the two generator rollouts of an iteration one after the other')
     ap.add_argument('--cpu-threads', type=int, default=16)
+    ap.add_argument('--ops-set', action='append', default=[], metavar='NAME=VALUE',
+                    help='A/B: set a module-level switch of generative_mouse_trajectories_amd.ops (e.g. GEN_BWD_SUMS_G0=0)')
     ap.add_argument('--no-mlp-kernels', action='store_true',
                     help='A/B: condition encoder and critic head as torch ops instead of csrc/mlp.hip')
     ap.add_argument('--no-real-overlap', action='store_true',
@@ -332,6 +334,11 @@ def main():
     if args.warmup is None:
         args.warmup = 8
 
+    for kv in args.ops_set:
+        from generative_mouse_trajectories_amd import ops as _ops
+        k, v = kv.split('=')
+        assert hasattr(_ops, k), k
+        setattr(_ops, k, type(getattr(_ops, k))(int(v)))
     if args.no_mlp_kernels:
         from generative_mouse_trajectories_amd import ops as _ops
         _ops.MLP_KERNELS = False

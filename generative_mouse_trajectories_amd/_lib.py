@@ -35,7 +35,7 @@ class GenFwdArgs(ctypes.Structure):
 class GenBwdArgs(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ('gates0', 'c0_all', 'gates1', 'c1_all', 'y_all', 'oraw_all', 'u_all', 'd_out',
                                    'w1T_pk', 'w_l1T_pk', 'w_hh0T_pk', 'w_uP', 'w2', 'tf_mask', 'd_ypre', 'd_o',
-                                   'd_in0')] + [('T', c_i), ('B', c_i), ('H', c_i), ('dropout_p', c_f),
+                                   'd_in0', 'd_g0')] + [('T', c_i), ('B', c_i), ('H', c_i), ('dropout_p', c_f),
                                                 ('seed', ctypes.c_uint)]
 
 

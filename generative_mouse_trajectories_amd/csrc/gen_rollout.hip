@@ -299,7 +299,11 @@ __device__ __forceinline__ void cell_bwd(float dht, float& dc, float ig, float f
 // Every operand of step t-1 is requested while step t's contractions run (one accumulator row of
 // loads ahead of a group of MFMAs): layer 0's saved gates under B4, layer 1's and the per-row
 // scalars under B6.  c_t is carried from the c_{t-1} fetch of the step before.
-template <int NW, bool RES0>
+// SUMG: d g0 = sum over t of d(pre-activation of layer 0) (g0 enters every step's gates) is accumulated in LDS - element
+// (row, unit) belongs to one lane for the whole launch, so a plain float4 read-modify-write per accumulator row and step
+// (~1 k of a step's ~80 k cycles) - and written once at the end: the separate reduction pass over gates0 [T, B, 4H]
+// (1 GB at B = 4096, T = 128: 0.45 ms as an ATen kernel) is gone.  Needs 32 x 4H floats of LDS: H <= 128.
+template <int NW, bool RES0, bool SUMG>
 __global__ __launch_bounds__(NW * 64, 1)
 void gen_bwd_kernel(gmt_gen_bwd_args a)
 {
@@ -312,10 +316,14 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
     float* doS = dyT + HH * GMT_LDA;                   // [3][32]
     constexpr bool WUL = (NW <= 4);                    // W_u [4H][8] (zero-padded) cached in LDS when it fits: read by every thread in B6
     float* wuS = doS + 96;
+    float* sgS = wuS + (WUL ? 4 * H * 8 : 0);          // [32][4H]  (SUMG)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * GMT_TM;
+    if constexpr (SUMG) {
+        for (int i = tid; i < GMT_TM * 4 * H; i += NT) sgS[i] = 0.f;
+    }
     const int hi = lane >> 5, lo = lane & 31;
     const int col = wave * 32 + lo;
     const int T = a.T, B = a.B;
@@ -474,6 +482,12 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
                 cell_bwd(acc2[1][r], dc0[r], g0[0][r], g0[1][r], g0[2][r], g0[3][r], cn0[r], cp, dai, daf, dag, dao);
                 cn0[r] = cp0[r];
                 gmt_st4(q, dai, daf, dag, dao);
+                if constexpr (SUMG) {
+                    float4* sp = reinterpret_cast<float4*>(sgS + (size_t)(mr + 4 * hi) * (4 * H) + 4 * col);
+                    float4 sv = *sp;
+                    sv.x += dai; sv.y += daf; sv.z += dag; sv.w += dao;
+                    *sp = sv;
+                }
                 dl[0 * H * GMT_LDA + mr] = dai; dl[1 * H * GMT_LDA + mr] = daf;
                 dl[2 * H * GMT_LDA + mr] = dag; dl[3 * H * GMT_LDA + mr] = dao;
             }
@@ -541,6 +555,15 @@ void gen_bwd_kernel(gmt_gen_bwd_args a)
             }
         }
     }
+    if constexpr (SUMG) {
+        // (each lane reads back only what it wrote itself: no barrier needed)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float4 sv = *reinterpret_cast<const float4*>(sgS + (size_t)row * (4 * H) + 4 * col);
+            *reinterpret_cast<float4*>(a.d_g0 + ((size_t)row0 + row) * (4 * H) + 4 * col) = sv;
+        }
+    }
     GMT_PH_DUMP;
 }
 
@@ -565,9 +588,11 @@ int launch_gen_bwd(const gmt_gen_bwd_args& a, hipStream_t stream)
 {
     constexpr int H = NW * 32, HH = H / 2;
     constexpr bool RES0 = (NW <= 2);             // at H >= 128 the prefetch registers need the room: W_hh_l0^T streams from L2
-    const size_t lds = ((size_t)(4 * H + HH) * GMT_LDA + 96 + (NW <= 4 ? 4 * H * 8 : 0)) * sizeof(float);
+    constexpr bool CAN_SUM = (NW <= 4);
+    if (a.d_g0 && !CAN_SUM) return GMT_ERR_UNSUPPORTED;
+    const size_t lds = ((size_t)(4 * H + HH) * GMT_LDA + 96 + (NW <= 4 ? 4 * H * 8 : 0) + (a.d_g0 ? GMT_TM * 4 * H : 0)) * sizeof(float);
     if (lds > 160 * 1024 - 256) return GMT_ERR_UNSUPPORTED;
-    auto k = gen_bwd_kernel<NW, RES0>;
+    auto k = (a.d_g0 && CAN_SUM) ? gen_bwd_kernel<NW, RES0, CAN_SUM> : gen_bwd_kernel<NW, RES0, false>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GMT_ERR_HIP;
     hipLaunchKernelGGL(k, dim3(a.B / GMT_TM), dim3(NW * 64), lds, stream, a);

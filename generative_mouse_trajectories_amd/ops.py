@@ -1146,6 +1146,7 @@ def gen_backward_packs(w_hh0, w_ih1, w_hh1, w1):
     return derived('gen_bwd_pk', [w_hh0, w_ih1, w_hh1, w1], build)
 
 
+GEN_BWD_SUMS_G0 = True                # False: d g0 by a separate reduction pass over gates0 (A/B switch)
 AFTER_GEN_BWD_LAUNCH: list = []       # at most one callable(event recorded just before the BPTT launch); one-shot
 
 
@@ -1242,6 +1243,10 @@ class GenRolloutFn(torch.autograd.Function):
         a.w_uP = w_uP.data_ptr(); a.w2 = w2c.data_ptr()
         a.tf_mask = tf_mask.data_ptr() if ctx.has_tf else None
         a.d_ypre = d_ypre.data_ptr(); a.d_o = d_o.data_ptr(); a.d_in0 = d_in0.data_ptr()
+        d_g0 = None
+        if GEN_BWD_SUMS_G0 and H <= 128:               # the kernel accumulates d g0 on chip (32 x 4H floats of LDS)
+            d_g0 = f(B, 4 * H)
+            a.d_g0 = d_g0.data_ptr()
         a.T, a.B, a.H = T, B, H
         a.dropout_p, a.seed = ctx.drop
         hook = AFTER_GEN_BWD_LAUNCH[0] if AFTER_GEN_BWD_LAUNCH else None
@@ -1260,7 +1265,8 @@ class GenRolloutFn(torch.autograd.Function):
         da0 = gates0.view(T * B, 4 * H)
         da1 = gates1.view(T * B, 4 * H)
         h0v, h1v = h0.view(T * B, H), h1.view(T * B, H)
-        d_g0 = gates0.sum(0)                                            # time-invariant input: sum over t (unit-major, like g0)
+        if d_g0 is None:
+            d_g0 = gates0.sum(0)                                        # time-invariant input: sum over t (unit-major, like g0)
         d_w_u = wgrad_gates(da0, u.view(T * B, 8))[0][:, :7]
         d_w_hh0 = wgrad_gates(da0[B:], h0v[:-B])[0] if T > 1 else torch.zeros_like(w_hh0)
         d_w_ih1, d_bias1 = wgrad_gates(da1, h0d.view(T * B, H), want_db=True)

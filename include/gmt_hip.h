@@ -444,6 +444,8 @@ typedef struct gmt_gen_bwd_args {
     float* d_ypre;           /* [T][B][HH] out */
     float* d_o;              /* [T][B][3] out: gradient of the head's raw output */
     float* d_in0;            /* [B][3] out: gradient of the initial input, per row */
+    float* d_g0;             /* [B][4H] out or NULL (H <= 128): gradient of g0 = sum over t of d(pre-activation of layer 0),
+                              * unit-major columns like g0 - accumulated on chip, no reduction pass over gates0 afterwards */
     int T, B, H;
     float dropout_p; unsigned int seed;   /* as in the forward launch */
 } gmt_gen_bwd_args;
