@@ -129,6 +129,10 @@ _SIGS = {
     'gmt_gen_loss_workspace_floats': [c_i, c_p],
     'gmt_gen_loss_fwd': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     'gmt_gen_loss_bwd': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_ll, c_i, c_i, c_i, c_p],
+    'gmt_critic_loss_fwd': [c_p, c_p, c_i, c_p, c_p, c_p],
+    'gmt_critic_loss_bwd': [c_p, c_i, c_i, c_p, c_p, c_p],
+    'gmt_gen_step_loss_finish': [c_p, c_p, c_f, c_i, c_f, c_f, c_p, c_p, c_p, c_p],
+    'gmt_gen_step_loss_bwd': [c_p, c_ll, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_ll, c_p, c_i, c_i, c_i, c_p],
     'gmt_spectral_norm_fwd': [c_p, c_i, c_f, c_i, c_p],
     'gmt_spectral_norm_bwd': [c_p, c_i, c_p],
     'gmt_gen_rollout_fwd': [c_p, c_p],

@@ -148,10 +148,15 @@ __global__ __launch_bounds__(LB)
 void gen_loss_bwd_kernel(const float* __restrict__ seq, long long sb, long long st, const float* __restrict__ starts,
                          const float* __restrict__ ends, const int* __restrict__ lengths,
                          const float* __restrict__ final_pos, const float* __restrict__ gscal,
-                         float* __restrict__ gseq, long long gsb, long long gst, int T, int B, int n_valid)
+                         float* __restrict__ gseq, long long gsb, long long gst, int T, int B, int n_valid,
+                         const float* __restrict__ gtot, float* __restrict__ d_score)
 {
+    // gtot != null (gmt_gen_step_loss_bwd): gscal holds the three coefficients of gen_step_finish_kernel, to be scaled
+    // by the adjoint of the total loss; d_score[b] = gtot * gscal[2] on the valid rows, 0 on the batch padding
     const int b = blockIdx.x * LB + threadIdx.x;
     if (b >= B) return;
+    const float gt = gtot ? gtot[0] : 1.0f;
+    if (d_score) d_score[b] = b < n_valid ? gt * gscal[2] : 0.f;
     float* o = gseq + (size_t)b * gsb;
     int len = 0;
     float ge_x = 0.f, ge_y = 0.f, gd = 0.f;
@@ -159,8 +164,8 @@ void gen_loss_bwd_kernel(const float* __restrict__ seq, long long sb, long long 
     if (b < n_valid) {
         len = lengths[b];
         len = len < 0 ? 0 : (len > T ? T : len);
-        const float g0 = gscal[0];
-        gd = gscal[1];
+        const float g0 = gt * gscal[0];
+        gd = gt * gscal[1];
         ge_x = 2.f * g0 * (final_pos[2 * b] - ends[2 * b]);
         ge_y = 2.f * g0 * (final_pos[2 * b + 1] - ends[2 * b + 1]);
         td = target_dir(starts[2 * b], starts[2 * b + 1], ends[2 * b], ends[2 * b + 1]);
@@ -180,7 +185,104 @@ void gen_loss_bwd_kernel(const float* __restrict__ seq, long long sb, long long 
     }
 }
 
+// The scalar arithmetic of train_generator_step after the reductions (RG.py:1069, 1072-1097), one thread:
+//   out[0] = -mean(score) (g_loss), out[1] = scal0 / (2B) (endpoint, F.mse_loss over (B, 2)), out[2] = num / den (direction;
+//   nd != null: the numerator / denominator summed over the ranks of a data-parallel run), out[3] = mean(score),
+//   total[0] = g_loss + w_e endpoint + w_d direction,
+//   coef[0..2] = d total / d scal0, d total / d (local) num, d total / d score_b  - what gen_loss_bwd_kernel multiplies
+//   by the adjoint of total (world / den: the ranks' gradients are averaged afterwards, see Trainer).
+__global__ __launch_bounds__(64)
+void gen_step_finish_kernel(const float* __restrict__ scal, const float* __restrict__ nd, float world, int B,
+                            float w_e, float w_d, float* __restrict__ total, float* __restrict__ out,
+                            float* __restrict__ coef)
+{
+    if (threadIdx.x == 0) {
+        const float fB = (float)B;
+        const float mean_s = scal[3] / fB;
+        const float g_loss = -mean_s;
+        const float endpoint = scal[0] / (2.0f * fB);
+        const float num = nd ? nd[0] : scal[1], den = nd ? nd[1] : scal[2];
+        const float direction = num / den;
+        out[0] = g_loss; out[1] = endpoint; out[2] = direction; out[3] = mean_s;
+        total[0] = g_loss + w_e * endpoint + w_d * direction;
+        coef[0] = w_e / (2.0f * fB);
+        coef[1] = w_d * (world / den);
+        coef[2] = -1.0f / fB;
+    }
+}
+
+// Critic loss of train_discriminator_step (RG.py:963): d_loss = mean(fake) - mean(real) over the B valid rows of the two
+// padded score vectors; out = (mean real, mean fake).  One block; fixed summation order.
+__global__ __launch_bounds__(LB)
+void critic_loss_fwd_kernel(const float* __restrict__ real, const float* __restrict__ fake, int B,
+                            float* __restrict__ loss, float* __restrict__ out)
+{
+    __shared__ float red[LB / 64][2];
+    float sr = 0.f, sf = 0.f;
+    for (int b = threadIdx.x; b < B; b += LB) { sr += real[b]; sf += fake[b]; }
+    sr = gmt_wave_sum(sr); sf = gmt_wave_sum(sf);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sr; red[threadIdx.x >> 6][1] = sf; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tr = 0.f, tf = 0.f;
+#pragma unroll
+        for (int w = 0; w < LB / 64; ++w) { tr += red[w][0]; tf += red[w][1]; }
+        const float mr = tr / (float)B, mf = tf / (float)B;
+        out[0] = mr; out[1] = mf;
+        loss[0] = mf - mr;
+    }
+}
+
+__global__ __launch_bounds__(LB)
+void critic_loss_bwd_kernel(const float* __restrict__ g, int B, int Bp, float* __restrict__ d_real, float* __restrict__ d_fake)
+{
+    const int b = blockIdx.x * LB + threadIdx.x;
+    if (b >= Bp) return;
+    const float v = b < B ? g[0] / (float)B : 0.f;
+    d_real[b] = -v;
+    d_fake[b] = v;
+}
+
 }  // namespace
+
+extern "C" int gmt_critic_loss_fwd(const float* real, const float* fake, int B, float* loss, float* out, hipStream_t stream)
+{
+    GMT_CHECK_ARG(real && fake && loss && out && B >= 1);
+    hipLaunchKernelGGL(critic_loss_fwd_kernel, dim3(1), dim3(LB), 0, stream, real, fake, B, loss, out);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+extern "C" int gmt_critic_loss_bwd(const float* g, int B, int Bp, float* d_real, float* d_fake, hipStream_t stream)
+{
+    GMT_CHECK_ARG(g && d_real && d_fake && B >= 1 && Bp >= B);
+    hipLaunchKernelGGL(critic_loss_bwd_kernel, dim3((Bp + LB - 1) / LB), dim3(LB), 0, stream, g, B, Bp, d_real, d_fake);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+extern "C" int gmt_gen_step_loss_finish(const float* scal, const float* nd, float world, int n_valid, float w_endpoint,
+                                        float w_direction, float* total, float* out, float* coef, hipStream_t stream)
+{
+    GMT_CHECK_ARG(scal && total && out && coef && n_valid >= 1 && world >= 1.0f);
+    hipLaunchKernelGGL(gen_step_finish_kernel, dim3(1), dim3(64), 0, stream, scal, nd, world, n_valid, w_endpoint,
+                       w_direction, total, out, coef);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
+
+extern "C" int gmt_gen_step_loss_bwd(const float* seq, long long stride_b, long long stride_t, const float* starts,
+                                     const float* ends, const int* lengths, const float* final_pos, const float* coef,
+                                     const float* g_total, float* gseq, long long gstride_b, long long gstride_t,
+                                     float* d_score, int T, int B, int n_valid, hipStream_t stream)
+{
+    GMT_CHECK_ARG(seq && starts && ends && lengths && final_pos && coef && g_total && gseq && d_score && T >= 1 && B >= 1 &&
+                  n_valid >= 0 && n_valid <= B);
+    hipLaunchKernelGGL(gen_loss_bwd_kernel, dim3((B + LB - 1) / LB), dim3(LB), 0, stream, seq, stride_b, stride_t, starts,
+                       ends, lengths, final_pos, coef, gseq, gstride_b, gstride_t, T, B, n_valid, g_total, d_score);
+    GMT_LAUNCH_CHECK();
+    return GMT_OK;
+}
 
 extern "C" int gmt_traj_from_seq(const float* seq, long long stride_b, long long stride_t, const float* starts,
                                  float* pos, float* dts, int T, int B, int n_valid, float first_dt, hipStream_t stream)
@@ -243,7 +345,7 @@ extern "C" int gmt_gen_loss_bwd(const float* seq, long long stride_b, long long 
     GMT_CHECK_ARG(seq && starts && ends && lengths && final_pos && gscal && gseq && T >= 1 && B >= 1 && n_valid >= 0 &&
                   n_valid <= B);
     hipLaunchKernelGGL(gen_loss_bwd_kernel, dim3((B + LB - 1) / LB), dim3(LB), 0, stream, seq, stride_b, stride_t, starts,
-                       ends, lengths, final_pos, gscal, gseq, gstride_b, gstride_t, T, B, n_valid);
+                       ends, lengths, final_pos, gscal, gseq, gstride_b, gstride_t, T, B, n_valid, nullptr, nullptr);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }

@@ -382,7 +382,8 @@ class Discriminator(nn.Module):
         `dropout_seed`, else drawn on the host), torch ops for widths outside the kernel's table."""
         ol = self.output_layers
         H = self.config.discriminator_hidden_dim
-        if (h_final.dtype == torch.float32 and ops.critic_head_supported(H) and h_final.shape[0] % ops.TM == 0
+        standard = (len(ol) == 6 and isinstance(ol[0], SNLinear) and isinstance(ol[2], nn.Dropout) and len(sn_w) == 3)
+        if (standard and h_final.dtype == torch.float32 and ops.critic_head_supported(H) and h_final.shape[0] % ops.TM == 0
                 and ol[1].negative_slope == ol[4].negative_slope):
             p = float(ol[2].p) if self.training else 0.0
             seed = 0

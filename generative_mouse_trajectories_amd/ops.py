@@ -854,6 +854,93 @@ def gen_aux_losses(seq_tm, starts, ends, lengths_i32):
     return GenAuxLossFn.apply(seq_tm, starts, ends, lengths_i32)
 
 
+STEP_LOSS_KERNELS = True        # False: the step functions' scalar loss arithmetic as torch ops (A/B switch)
+
+
+class GenStepLossFn(torch.autograd.Function):
+    """The whole loss of train_generator_step (RG.py:1069-1097) from the rollout and the critic's padded score vector:
+    (seq_tm [T,Bp,3], score [Bp,1], starts [B,2], ends [B,2], lengths int32 [B], w_endpoint, w_direction, reduce) ->
+    total [] (differentiable), parts [4] = (g_loss, endpoint_loss, direction_loss, mean score) (not differentiable).
+    Three launches forward (reductions, their fixed-order finish, the combination), one backward (d total / d seq and
+    d total / d score together).  `reduce` (data-parallel runs): callable that sums a [2] tensor (direction numerator and
+    denominator) over the ranks in place and returns the number of ranks - RG.py:1095 divides by the mask sum of the
+    WHOLE batch, and the ranks' gradients are averaged afterwards, hence the factor world / den in the coefficients."""
+
+    @staticmethod
+    def forward(ctx, seq_tm, score, starts, ends, lengths, w_e, w_d, reduce):
+        L_.require_cuda(seq_tm, score, starts, ends, lengths)
+        import ctypes
+        seq_tm = seq_tm.contiguous()
+        T, Bp, _ = seq_tm.shape
+        B = starts.shape[0]
+        score = score.detach().contiguous()
+        assert score.numel() == Bp and lengths.dtype == torch.int32 and lengths.numel() == B
+        starts, ends = starts.contiguous().float(), ends.contiguous().float()
+        dev = seq_tm.device
+        f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+        need = ctypes.c_longlong(0)
+        L_.call('gmt_gen_loss_workspace_floats', B, ctypes.addressof(need), label='skip')
+        ws, final, scal = f(need.value), f(B, 2), f(4)
+        L_.call('gmt_gen_loss_fwd', L_.ptr(seq_tm), 3, 3 * Bp, L_.ptr(starts), L_.ptr(ends), L_.ptr(lengths), L_.ptr(score),
+                L_.ptr(final), L_.ptr(scal), L_.ptr(ws), T, B, L_.stream())
+        nd, world = None, 1.0
+        if reduce is not None:
+            nd = scal[1:3].clone()
+            world = float(reduce(nd))
+        total, parts, coef = f(()), f(4), f(3)
+        L_.call('gmt_gen_step_loss_finish', L_.ptr(scal), L_.ptr(nd), world, B, float(w_e), float(w_d), L_.ptr(total),
+                L_.ptr(parts), L_.ptr(coef), L_.stream())
+        ctx.save_for_backward(seq_tm, starts, ends, lengths, final, coef)
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        seq_tm, starts, ends, lengths, final, coef = ctx.saved_tensors
+        T, Bp, _ = seq_tm.shape
+        B = starts.shape[0]
+        g = g_total.contiguous().float()
+        gseq = torch.empty_like(seq_tm)
+        d_score = torch.empty(Bp, 1, device=seq_tm.device, dtype=torch.float32)
+        L_.call('gmt_gen_step_loss_bwd', L_.ptr(seq_tm), 3, 3 * Bp, L_.ptr(starts), L_.ptr(ends), L_.ptr(lengths), L_.ptr(final),
+                L_.ptr(coef), L_.ptr(g), L_.ptr(gseq), 3, 3 * Bp, L_.ptr(d_score), T, Bp, B, L_.stream())
+        return gseq, d_score, None, None, None, None, None, None
+
+
+def gen_step_loss(seq_tm, score_padded, starts, ends, lengths_i32, w_endpoint: float, w_direction: float, reduce=None):
+    return GenStepLossFn.apply(seq_tm, score_padded, starts, ends, lengths_i32, w_endpoint, w_direction, reduce)
+
+
+class CriticLossFn(torch.autograd.Function):
+    """d_loss = mean(fake) - mean(real) (RG.py:963) over the first B rows of two padded score vectors [Bp,1]:
+    -> loss [] (differentiable), parts [2] = (mean real, mean fake); one launch each way (zeros on the padding rows)."""
+
+    @staticmethod
+    def forward(ctx, real, fake, B):
+        L_.require_cuda(real, fake)
+        real, fake = real.detach().contiguous(), fake.detach().contiguous()
+        assert real.numel() == fake.numel() and real.numel() >= B
+        loss = torch.empty((), device=real.device, dtype=torch.float32)
+        parts = torch.empty(2, device=real.device, dtype=torch.float32)
+        L_.call('gmt_critic_loss_fwd', L_.ptr(real), L_.ptr(fake), int(B), L_.ptr(loss), L_.ptr(parts), L_.stream())
+        ctx.meta = (int(B), real.numel(), tuple(real.shape))
+        ctx.mark_non_differentiable(parts)
+        return loss, parts
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        B, Bp, shape = ctx.meta
+        g = g.contiguous().float()
+        d_real = torch.empty(shape, device=g.device, dtype=torch.float32)
+        d_fake = torch.empty(shape, device=g.device, dtype=torch.float32)
+        L_.call('gmt_critic_loss_bwd', L_.ptr(g), B, Bp, L_.ptr(d_real), L_.ptr(d_fake), L_.stream())
+        return d_real, d_fake, None
+
+
+def critic_loss(real_padded, fake_padded, B: int):
+    return CriticLossFn.apply(real_padded, fake_padded, B)
+
+
 # ----------------------------------------------------------------------------------------
 # the two small dense stacks (csrc/mlp.hip): generator condition encoder, critic output head
 # ----------------------------------------------------------------------------------------
@@ -1009,12 +1096,18 @@ class CriticHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_score):
-        if torch.is_grad_enabled():
-            raise NotImplementedError('CriticHeadFn: first-order backward only (composite.discriminator_forward_gp is the '
-                                      'twice-differentiable critic)')
         x, w1, w2, w3, a1, a2 = ctx.saved_tensors
         Bp, H, a2p, slope, p, seed = ctx.meta
         N2 = H // 2
+        if torch.is_grad_enabled():
+            # create_graph=True: the same backward out of torch ops, which autograd can differentiate once more (the
+            # masks are constants: LeakyReLU'' = 0).  Not a hot path - the penalty uses composite.discriminator_forward_gp.
+            m2 = torch.where(a2[:, :N2] > 0, 1.0, slope)
+            m1 = torch.where(a1 > 0, 1.0, slope) * ((a1 != 0).float() / (1.0 - p) if p > 0 else 1.0)
+            dy2 = (d_score @ w3) * m2
+            dy1 = (dy2 @ w2) * m1
+            return (dy1 @ w1, dy1.t() @ x, dy1.sum(0), dy2.t() @ a1, dy2.sum(0), d_score.t() @ a2[:, :N2], d_score.sum(0),
+                    None, None, None)
         dev = x.device
         f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
         ds = d_score.contiguous()
@@ -1275,7 +1368,7 @@ class GenRolloutFn(torch.autograd.Function):
         d_w1, d_b1 = wgrad(dyp, h1v, want_db=True)
         dov = d_o.view(T * B, 3)
         d_w2 = wgrad(y.view(T * B, HH), dov)[0].t()                    # [3,HH] via its transpose: N = HH, skinny X = d_o
-        d_b2 = dov.sum(0)
+        d_b2 = d_o.sum(0).sum(0)                                        # (two well-shaped reductions: [T, B*3] then [B, 3]; 0.18 -> 0.02 ms)
         d_init = d_in0.sum(0).reshape(ctx.init_shape)
         return (d_g0, d_w_u, d_w_hh0, d_w_ih1, d_w_hh1, d_bias1, d_w1, d_b1, d_w2, d_b2, d_init,
                 None, None, None, None, None, None, None, None, None, None, None)

@@ -516,8 +516,10 @@ class Trainer:
 
     def _metrics(self, keys, scalars: List[torch.Tensor], extra: Optional[Dict[str, float]] = None) -> StepMetrics:
         """The step's device scalars -> one pinned-memory copy on the stream + an event; see StepMetrics."""
-        dev_vals = torch.stack([s_.detach().float().reshape(()) for s_ in scalars])
-        host = torch.empty(len(scalars), dtype=torch.float32, pin_memory=True)
+        # (entries may be vectors: the loss kernels hand several metrics over as one tensor)
+        dev_vals = scalars[0].detach().float().reshape(-1) if len(scalars) == 1 else \
+            torch.cat([s_.detach().float().reshape(-1) for s_ in scalars])
+        host = torch.empty(dev_vals.numel(), dtype=torch.float32, pin_memory=True)
         host.copy_(dev_vals, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -526,6 +528,13 @@ class Trainer:
         while len(self._in_flight) > max(0, int(self.max_steps_in_flight)):
             self._in_flight.pop(0).wait()
         return m
+
+    def _zero_scalar(self) -> torch.Tensor:
+        """A constant 0-d zero on the device (the d_gp metric of the steps without a penalty): made once, never written."""
+        z = getattr(self, '_zero0', None)
+        if z is None or z.device != self.device:
+            z = self._zero0 = torch.zeros((), device=self.device)
+        return z
 
     def _to_dev(self, batch: Dict):
         d = self.device
@@ -577,7 +586,7 @@ class Trainer:
             Bp = ops.pad_rows(batch_size, ops.row_tile(self.config))
             real_pos, real_dts = ops.traj_from_seq(sequences.float(), starts, False, batch_size, Bp)
             lens_p1 = self._critic_inputs(lengths, Bp, next_batch['lengths'], sequences.shape[1])
-            real_score = D.forward_tm(real_pos, real_dts, lens_p1)[:batch_size]
+            real_score = D.forward_tm(real_pos, real_dts, lens_p1)               # padded [Bp, 1]
         self._spec_real = {'batch': next_batch, 'd_version': self._d_version, 'training': D.training, 'stream': other,
                            'real_pos': real_pos, 'real_dts': real_dts, 'lens_p1': lens_p1, 'real_score': real_score}
 
@@ -630,10 +639,16 @@ class Trainer:
             fake_tm = G.forward_tm(starts, ends, z, sequences, [False] * T)              # (T,Bp,3), RG.py:938-944
             fake_pos, fake_dts = ops.traj_from_seq(fake_tm, starts, True, batch_size, Bp)     # RG.py:946-949
         lens_p1 = self._critic_inputs(lengths, Bp, real_batch['lengths'], T)
-        real_score = spec_r['real_score'] if spec_r is not None else D.forward_tm(real_pos, real_dts, lens_p1)[:batch_size]
-        fake_score = D.forward_tm(fake_pos, fake_dts, lens_p1)[:batch_size]              # fake_lengths == lengths (RG.py:599-600)
-        d_loss = fake_score.mean() - real_score.mean()
-        gp = torch.zeros((), device=self.device)
+        real_score_p = spec_r['real_score'] if spec_r is not None else D.forward_tm(real_pos, real_dts, lens_p1)
+        fake_score_p = D.forward_tm(fake_pos, fake_dts, lens_p1)                         # fake_lengths == lengths (RG.py:599-600)
+        if ops.STEP_LOSS_KERNELS:
+            # mean(fake) - mean(real) over the valid rows and both score means: one launch (one more for the backward)
+            d_loss, score_means = ops.critic_loss(real_score_p, fake_score_p, batch_size)
+        else:
+            real_score, fake_score = real_score_p[:batch_size], fake_score_p[:batch_size]
+            d_loss = fake_score.mean() - real_score.mean()
+            score_means = torch.stack([real_score.detach().mean(), fake_score.detach().mean()])
+        gp = self._zero_scalar()
         do_gp = (self.d_step % max(1, cfg.gp_every_n) == 0)
         self.d_step += 1
         if do_gp:
@@ -651,14 +666,13 @@ class Trainer:
             gp = compute_gradient_penalty(D, sel(real_pos), sel(fake_pos), sel(real_dts), sel(fake_dts),
                                           (lengths + 1).index_select(0, idx), self.device,
                                           None if alpha is None else alpha.to(self.device))
-        total_loss = d_loss + cfg.gradient_penalty_weight * gp
+        total_loss = d_loss + cfg.gradient_penalty_weight * gp if do_gp else d_loss
         self._backward_and_sync(total_loss, self.d_flat, self._d_sync)
         self.d_optimizer.step()
         self._d_version += 1
         if self.host_clock is not None:
             self.host_clock.append(('d_enqueued', __import__('time').perf_counter()))
-        return self._metrics(('d_loss', 'd_gp', 'd_real_score', 'd_fake_score'),
-                             [d_loss, gp, real_score.detach().mean(), fake_score.detach().mean()])
+        return self._metrics(('d_loss', 'd_gp', 'd_real_score', 'd_fake_score'), [d_loss, gp, score_means])
 
     # ---- generator step (RecurrentGAN.py:1031-1118) ---------------------------------
     def train_generator_step(self, real_batch: Dict, noise: Optional[Dict] = None,
@@ -698,10 +712,22 @@ class Trainer:
         for p in d_params:
             p.requires_grad_(False)
         try:
-            fake_score = D.forward_tm(fake_pos, fake_dts, self._critic_inputs(lengths, Bp, real_batch['lengths'], T))[:batch_size]   # RG.py:1064
+            fake_score_p = D.forward_tm(fake_pos, fake_dts, self._critic_inputs(lengths, Bp, real_batch['lengths'], T))   # RG.py:1064
         finally:
             for p in d_params:
                 p.requires_grad_(True)
+        if ops.STEP_LOSS_KERNELS:
+            # RG.py:1069-1097 - adversarial, endpoint and direction terms, their weighted sum and (backward) the adjoints of
+            # the rollout and of the score vector - in the loss kernels; a data-parallel run sums the direction term's
+            # numerator and denominator over the ranks in between (RG.py:1095 divides by the mask sum of the WHOLE batch)
+            reduce = None
+            if self.world_size > 1:
+                import torch.distributed as dist
+                reduce = lambda nd: (all_reduce_sum(nd, self.process_group), dist.get_world_size(self.process_group))[1]
+            total_loss, parts = ops.gen_step_loss(fake_tm, fake_score_p, starts, ends, lengths.to(torch.int32),
+                                                  cfg.endpoint_loss_weight, cfg.direction_loss_weight, reduce)
+            return self._finish_generator_step(total_loss, [parts], next_batch, tf_ratio)
+        fake_score = fake_score_p[:batch_size]
         g_loss = -fake_score.mean()                                                              # RG.py:1069
         # endpoint and direction losses (RG.py:1072-1095): every reduction in one kernel, gradient in one more
         scal = ops.gen_aux_losses(fake_tm, starts, ends, lengths.to(torch.int32))
@@ -719,6 +745,10 @@ class Trainer:
             direction_loss = nd[0] / nd[1]
             dir_for_grad = dir_num * (float(dist.get_world_size(self.process_group)) / nd[1])
         total_loss = g_loss + cfg.endpoint_loss_weight * endpoint_loss + cfg.direction_loss_weight * dir_for_grad
+        return self._finish_generator_step(total_loss, [g_loss, endpoint_loss, direction_loss, fake_score.detach().mean()],
+                                           next_batch, tf_ratio)
+
+    def _finish_generator_step(self, total_loss, metric_tensors, next_batch, tf_ratio) -> Dict[str, float]:
         if next_batch is not None and self.discriminator.training:
             self._main_stream = torch.cuda.current_stream()
             ops.AFTER_GEN_BWD_LAUNCH[:] = [lambda ev, nb=next_batch: self._launch_speculative_real_forward(nb, ev)]
@@ -730,8 +760,7 @@ class Trainer:
         self._g_version += 1
         if self.host_clock is not None:
             self.host_clock.append(('g_enqueued', __import__('time').perf_counter()))
-        return self._metrics(('g_loss', 'g_endpoint_loss', 'g_direction_loss', 'g_fake_score'),
-                             [g_loss, endpoint_loss, direction_loss, fake_score.detach().mean()],
+        return self._metrics(('g_loss', 'g_endpoint_loss', 'g_direction_loss', 'g_fake_score'), metric_tensors,
                              {'teacher_forcing_ratio': tf_ratio})
 
     # ---- epoch / run loop (RecurrentGAN.py:1120-1303) -------------------------------

@@ -119,6 +119,25 @@ int gmt_gen_loss_bwd(const float* seq, long long stride_b, long long stride_t, c
                      float* gseq, long long gstride_b, long long gstride_t, int T, int B, int n_valid,
                      hipStream_t stream);
 
+/* The scalar arithmetic of the two step functions, so that no element-wise torch kernels sit between the critic call and
+ * the backward pass (~45 launches per iteration otherwise).  They have the reference's arithmetic order.
+ * gmt_critic_loss_fwd / _bwd: d_loss = mean(fake) - mean(real) of RG.py:963 over the B valid rows of two padded score
+ *   vectors; out = (mean real, mean fake) (the d_real_score / d_fake_score metrics of RG.py:1024-1027); backward writes
+ *   -+ g / B on the valid rows and zeros on the padding.
+ * gmt_gen_step_loss_finish (after gmt_gen_loss_fwd with the score vector given: scal[4]): total = g_loss + w_endpoint endpoint + w_direction direction (RG.py:1097), out = (g_loss,
+ *   endpoint, direction, mean score), coef = the three factors the backward kernel scales by the adjoint of total;
+ *   nd (or NULL) = the direction numerator / denominator summed over the ranks of a data-parallel run, world = their
+ *   number (RG.py:1095 divides by the mask sum of the whole batch).
+ * gmt_gen_step_loss_bwd: gradient of total wrt the rollout (gseq [T][B][3]) and wrt the padded score vector, one launch. */
+int gmt_critic_loss_fwd(const float* real, const float* fake, int B, float* loss, float* out, hipStream_t stream);
+int gmt_critic_loss_bwd(const float* g, int B, int Bp, float* d_real, float* d_fake, hipStream_t stream);
+int gmt_gen_step_loss_finish(const float* scal, const float* nd, float world, int n_valid, float w_endpoint,
+                             float w_direction, float* total, float* out, float* coef, hipStream_t stream);
+int gmt_gen_step_loss_bwd(const float* seq, long long stride_b, long long stride_t, const float* starts,
+                          const float* ends, const int* lengths, const float* final_pos, const float* coef,
+                          const float* g_total, float* gseq, long long gstride_b, long long gstride_t,
+                          float* d_score, int T, int B, int n_valid, hipStream_t stream);
+
 /* ---- telemetry kinematics, "mode B", f64 ----------------------------------------------
  * Replaces MouseCollector::calculate_collection_attributes, MT.rs:550-654
  * (constants MT.rs:31,33).  x, y, tm: [n_max][n_traj] planes (time-major, padded);
