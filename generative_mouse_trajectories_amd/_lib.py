@@ -97,6 +97,7 @@ _SIGS = {
     'gmt_pack_weight': [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_ll, c_ll, c_p],
     'gmt_lstm_layer_fwd': [c_p] * 10 + [c_i] * 5 + [c_f, ctypes.c_uint, c_p],
     'gmt_lstm_layer_bwd': [c_p] * 11 + [c_i] * 4 + [c_f, ctypes.c_uint, c_p],
+    'gmt_lstm_layer_bwd_fx': [c_p] * 8 + [c_i] * 5 + [c_f, ctypes.c_uint, c_p],
     'gmt_lstm_layer_bwd2': [c_p] * 12 + [c_i] * 5 + [c_p],
     'gmt_lstm16_supported': [c_i, c_i],
     'gmt_lstm16_layer_fwd': [c_p] * 7 + [c_i] * 4 + [c_p],

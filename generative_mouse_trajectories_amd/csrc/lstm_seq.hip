@@ -284,9 +284,18 @@ void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ preg
 // no per-row pointer tests in the element-wise phase.
 // DY: 0 no dh_all (the top layer, whose only adjoint is dh_final); 1 dh_all is given; 2 dh_all is given and is
 // the adjoint of the DROPPED output (inter-layer dropout fused into the consumer): the keep mask is applied here.
+// DY 3 / 4 = 1 / 2 with dh_all given as PAIRS [L][B][ndir*H][2] whose two slots are added here: the partial input
+// gradients the two directions of the layer above wrote with FX (below).
 // EXTRA (gradient penalty, second backward): dgates_extra and dc_extra are both given and are prefetched
 // with the other operands; given singly they are read at use.
-template <int NW, bool RES, bool PLAIN, int DY, bool EXTRA>
+// FX (H = 128, plain call): the layer's INPUT gradient is contracted in the same time loop - after step t's
+// dh_prev = da_t W_hh, the tile of da_t that already sits in LDS meets W_ih (streamed from L2 in fragment-major order,
+// like the forward kernel's x-part): dx_t = da_t W_ih, 2 x 256 more MFMAs per wave and step at I = 2H.  The element-wise
+// phase of a step (~9 k cycles that nothing hides with one wave per SIMD) is then amortised over three times the matrix
+// work, d(pre-activation) is not read back from HBM by a separate contraction, and that contraction's launch is gone.
+// The two directions run in different workgroups with opposite time orders, so each writes its own slot of a pair
+// ([L*B][I][2], slot = direction); the consumer - the sweep of the layer below, DY 3 / 4 - adds the two at use.
+template <int NW, bool RES, bool PLAIN, int DY, bool EXTRA, int FX = 0>
 __global__ __launch_bounds__(NW * 64, 1)
 void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, const float* __restrict__ c_all,
                      const float* __restrict__ w_hh_pkT, const int* __restrict__ lengths,
@@ -297,11 +306,15 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
                      float* __restrict__ da_out /* null: overwrite `gates` in place */,
                      float* __restrict__ dct_out /* [ndir][L][B][H] or null: total cell adjoint (double backward) */,
                      float* __restrict__ dht_out /* [ndir][L][B][H] or null: total hidden adjoint (double backward) */,
-                     int L, int B, int ndir, int n_tiles, float dy_drop_p, uint32_t dy_drop_seed)
+                     int L, int B, int ndir, int n_tiles, float dy_drop_p, uint32_t dy_drop_seed,
+                     const float* __restrict__ w_ih_pkT /* FX: [ndir] blocks, K = 4H (gate-major), N = FX * 128 */,
+                     float* __restrict__ dx_pairs /* FX: [L*B][FX * 128][2] */)
 {
     constexpr int H = NW * 32;
     constexpr int KS = 2 * H;                          // k-steps over K = 4H
     constexpr bool HAS_DY = DY > 0;
+    constexpr bool PAIRS = DY >= 3, DROP = (DY == 2 || DY == 4);
+    static_assert(FX == 0 || (PLAIN && NW == 4), "fused input gradient: plain H = 128 call");
     const uint32_t dy_thresh16 = (uint32_t)(dy_drop_p * 65536.0f);
     const float dy_keep_scale = 1.0f / (1.0f - dy_drop_p);
     // at H = 128 the last KL k-steps of W_hh^T live in LDS, not registers (the prefetch registers need the room)
@@ -354,6 +367,7 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
     // their issue slots nor their HBM latency are exposed.  c_t is carried from the previous
     // step's c_prev fetch.
     float pg[4][16], pcp[16], pdy[16], cn_c[16];
+    float pdy2[PAIRS ? 16 : 1];
     float pge[EXTRA ? 4 : 1][16], pce[16];             // EXTRA: adjoints of the saved gates / cells of the next step
     auto prefetch_row = [&](int t, int r) {
         const int tp = dir ? t + 1 : t - 1;
@@ -365,7 +379,10 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
         // raw (tp outside [0, L): c_t itself, unused - selected away at use; touching a loaded value
         // here would wait for it on the spot)
         pcp[r] = c_all[(((size_t)dir * L + (tp_ok ? tp : t)) * B + lane_row + mr) * H + col];
-        if constexpr (HAS_DY) pdy[r] = dh_all[((size_t)t * B + lane_row + mr) * (ndir * H) + dir * H + col];
+        if constexpr (PAIRS) {
+            const float2 q2 = *reinterpret_cast<const float2*>(dh_all + 2 * (((size_t)t * B + lane_row + mr) * (ndir * H) + dir * H + col));
+            pdy[r] = q2.x; pdy2[r] = q2.y;
+        } else if constexpr (HAS_DY) pdy[r] = dh_all[((size_t)t * B + lane_row + mr) * (ndir * H) + dir * H + col];
         else pdy[r] = 0.f;
         if constexpr (EXTRA) {
             const float4 e = gmt_ld4(dgates_extra + (rs + mr) * (4 * H) + 4 * col);
@@ -419,10 +436,12 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
                 const float ig = pg[0][r], fg = pg[1][r], gg = pg[2][r], og = pg[3][r];
                 const float cn = cn_c[r];
                 const float cp = (has_prev && tp_in) ? pcp[r] : 0.f;
-                float dht = dh[r] + pdy[r];
-                if constexpr (DY == 2) {               // same element index as the consumer's x staging
+                float dyv = pdy[r];
+                if constexpr (PAIRS) dyv += pdy2[r];
+                float dht = dh[r] + dyv;
+                if constexpr (DROP) {                  // same element index as the consumer's x staging
                     const uint32_t i = (uint32_t)(((size_t)t * B + lane_row + mr) * (ndir * H)) + dir * H + col;
-                    dht = dh[r] + (gmt_keep16(i, dy_drop_seed, dy_thresh16) ? pdy[r] * dy_keep_scale : 0.f);
+                    dht = dh[r] + (gmt_keep16(i, dy_drop_seed, dy_thresh16) ? dyv * dy_keep_scale : 0.f);
                 }
                 const float tc = gmt_tanh(cn);
                 float dog = dht * tc;
@@ -477,6 +496,22 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = acc[0][r];
         GMT_PH(3);
+        if constexpr (FX > 0) {
+            // dx_t = da_t W_ih: this wave's columns g * 128 + col, g < FX (da of padded steps / rows is zero, so is dx)
+            f32x16 accx[FX];
+#pragma unroll
+            for (int g = 0; g < FX; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accx[g][r] = 0.f;
+            const float4* wx = reinterpret_cast<const float4*>(w_ih_pkT) + ((size_t)dir * NW + wave) * (4 * H / 8) * FX * 64;
+            gmt_mma_stream<FX>(accx, daT, wx, 4 * H, lane);
+            float* xo = dx_pairs + 2 * (((size_t)t * B + lane_row) * (FX * 128) + col) + dir;
+#pragma unroll
+            for (int g = 0; g < FX; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    xo[2 * ((size_t)((r & 3) + 8 * (r >> 2)) * (FX * 128) + g * 128)] = accx[g][r];
+        }
         __syncthreads();
         GMT_PH(4);
     }
@@ -487,6 +522,13 @@ void lstm_bwd_kernel(float* __restrict__ gates /* in: i,f,g,o   out: da */, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             gmt_st4(gp + (size_t)((r & 3) + 8 * (r >> 2)) * (4 * H), 0.f, 0.f, 0.f, 0.f);
+        }
+        if constexpr (FX > 0) {
+            float* xo = dx_pairs + 2 * (((size_t)t * B + lane_row) * (FX * 128) + col) + dir;
+#pragma unroll
+            for (int g = 0; g < FX; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xo[2 * ((size_t)((r & 3) + 8 * (r >> 2)) * (FX * 128) + g * 128)] = 0.f;
         }
     }
 }
@@ -525,7 +567,8 @@ template <int NW>
 int launch_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths, const float* dh_all,
                const float* dh_final, const float* dgates_extra, const float* dc_extra,
                float* da_out, float* dct_out, float* dht_out, int L, int B, int ndir,
-               float dy_drop_p, uint32_t dy_drop_seed, hipStream_t stream)
+               float dy_drop_p, uint32_t dy_drop_seed, hipStream_t stream,
+               int dh_pairs = 0, const float* w_ih_pkT = nullptr, float* dx_pairs = nullptr, int dx_n = 0)
 {
     constexpr int H = NW * 32;
     constexpr bool RES = (NW <= 4);
@@ -540,11 +583,27 @@ int launch_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const in
                            : dh_all ? lstm_bwd_kernel<NW, RES, true, 1, false> : lstm_bwd_kernel<NW, RES, true, 0, false>)
            : extra ? (dh_all ? lstm_bwd_kernel<NW, RES, false, 1, true> : lstm_bwd_kernel<NW, RES, false, 0, true>)
                    : (dh_all ? lstm_bwd_kernel<NW, RES, false, 1, false> : lstm_bwd_kernel<NW, RES, false, 0, false>);
+    if (dh_pairs || dx_pairs) {
+        // the fused-input-gradient pair of calls (gmt_lstm_layer_bwd_fx): producer = top layer (no dh_all) at H = 128
+        // writing I = 2H columns, consumer = the layer below reading the pairs
+        if constexpr (NW == 4) {
+            if (!plain) return GMT_ERR_UNSUPPORTED;
+            if (dx_pairs) {
+                if (dh_all || dx_n != 2 * H || !w_ih_pkT) return GMT_ERR_UNSUPPORTED;
+                k = lstm_bwd_kernel<NW, RES, true, 0, false, 2>;
+            } else {
+                if (!dh_all) return GMT_ERR_BAD_ARG;
+                k = drop ? lstm_bwd_kernel<NW, RES, true, 4, false> : lstm_bwd_kernel<NW, RES, true, 3, false>;
+            }
+        } else {
+            return GMT_ERR_UNSUPPORTED;
+        }
+    }
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GMT_ERR_HIP;
     hipLaunchKernelGGL(k, dim3(n_tiles * ndir), dim3(NW * 64), lds, stream, gates, c_all, w_hh_pkT, lengths,
                        dh_all, dh_final, dgates_extra, dc_extra, da_out, dct_out, dht_out, L, B, ndir, n_tiles,
-                       dy_drop_p, dy_drop_seed);
+                       dy_drop_p, dy_drop_seed, w_ih_pkT, dx_pairs);
     GMT_LAUNCH_CHECK();
     return GMT_OK;
 }
@@ -579,6 +638,21 @@ extern "C" int gmt_lstm_layer_fwd(const float* x, const float* pregates, const f
 #undef GMT_CASE
         default: return GMT_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" int gmt_lstm_layer_bwd_fx(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths,
+                                     const float* dh_pairs, const float* dh_final, const float* w_ih_pkT, float* dx_pairs,
+                                     int L, int B, int H, int I, int ndir, float dy_dropout_p, unsigned dy_dropout_seed,
+                                     hipStream_t stream)
+{
+    GMT_CHECK_ARG(dy_dropout_p >= 0.f && dy_dropout_p < 1.f);
+    GMT_CHECK_ARG(gates && c_all && w_hh_pkT && L >= 1 && B >= GMT_TM && (B % GMT_TM) == 0 && (ndir == 1 || ndir == 2));
+    GMT_CHECK_ARG((dh_pairs != nullptr) != (dx_pairs != nullptr));      // consumer or producer
+    GMT_CHECK_ARG(!dx_pairs || (w_ih_pkT && (((uintptr_t)w_ih_pkT | (uintptr_t)dx_pairs) & 15) == 0));
+    GMT_CHECK_ARG(!dh_pairs || (((uintptr_t)dh_pairs) & 7) == 0);
+    if (H != 128) return GMT_ERR_UNSUPPORTED;
+    return launch_bwd<4>(gates, c_all, w_hh_pkT, lengths, dh_pairs, dh_final, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         L, B, ndir, dy_dropout_p, dy_dropout_seed, stream, dh_pairs ? 1 : 0, w_ih_pkT, dx_pairs, I);
 }
 
 extern "C" int gmt_lstm_layer_bwd(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths,

@@ -366,6 +366,11 @@ class Discriminator(nn.Module):
             dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         none = (0.0, 0)
         h_final = None
+        if nl == 2 and fused_enc and self.fuse_input_gemm and (fused or p == 0) and ops.lstm_stack2_supported(H, 2):
+            # H = 128: both layers as one node whose backward contracts the top layer's input gradient inside its sweep
+            h_final = ops.lstm_stack2(x, lengths_i32, self.lstm.layer_weights(0), self.lstm.layer_weights(1),
+                                      (p, dropout_seed + 1) if fused else none, slope)
+            return self.head(h_final, sn_w, dropout_seed)
         for l in range(nl):
             h_all, h_final = ops.lstm_layer(x, lengths_i32, self.lstm.layer_weights(l), fuse_x=self.fuse_input_gemm,
                                             in_drop=(p, dropout_seed + l) if fused and l > 0 else none,

@@ -385,6 +385,102 @@ def lstm_layer(x, lengths_i32, weights, fuse_x: bool = True, need_h_all: bool = 
     return LSTMLayerFn.apply(x, lengths_i32, fuse_x, need_h_all, in_drop, out_drop, x_act_slope, *weights)
 
 
+LSTM_STACK_FUSED_DX = True       # False: the two layers as separate nodes with a separate input-gradient contraction (A/B switch)
+
+
+def lstm_stack2_supported(H: int, nd: int) -> bool:
+    return LSTM_STACK_FUSED_DX and H == 128 and nd == 2
+
+
+class LSTMStack2Fn(torch.autograd.Function):
+    """The critic's two-layer bidirectional LSTM (RG.py:720-727 applied at RG.py:772) as ONE autograd node, H = 128:
+    (x [L,B,H], lengths int32 [B], drop = (p, seed) of the inter-layer dropout, x_act_slope, layer-0 weights, layer-1
+    weights) -> h_final [B, 2H] of the top layer (all the critic head reads, RG.py:774-781).
+    Forward = the two persistent layer launches of LSTMLayerFn.  Backward: the top layer's sweep also contracts its INPUT
+    gradient (gmt_lstm_layer_bwd_fx: dx_t = da_t W_ih inside the time loop, written as per-direction pairs), the bottom
+    layer's sweep adds the pairs while it reads them - no separate dx contraction, no second pass over the top layer's
+    d(pre-activation), and the element-wise phase of the top sweep amortised over three times the matrix work.  One node,
+    because the pair buffer is not a gradient autograd could be handed."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, drop, x_act_slope, *weights):
+        L_.require_cuda(x)
+        nd = 2
+        w0, w1 = weights[:4 * nd], weights[4 * nd:]
+        H = w0[1].shape[1]
+        L, B, I = x.shape
+        assert B % TM == 0 and I == H and len(w1) == 4 * nd
+        x = x.contiguous()
+        dev = x.device
+        f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+        saved = []
+        inp, I_l = x, I
+        for l, w in enumerate((w0, w1)):
+            w_ih = [w[4 * d] for d in range(nd)]
+            w_hh = [w[4 * d + 1] for d in range(nd)]
+            bias = lstm_bias(w, nd)
+            w_hh_pk = derived('hh_pk', w_hh, lambda: pack_forward(w_hh, H, H))
+            w_ih_pk = derived('ih_pk', w_ih, lambda: pack_forward(w_ih, H, I_l))
+            gates, c_all, h_all, h_final = f(nd, L, B, 4 * H), f(nd, L, B, H), f(L, B, nd * H), f(B, nd * H)
+            in_drop = drop if l == 1 else (0.0, 0)
+            L_.call('gmt_lstm_layer_fwd', L_.ptr(inp), None, L_.ptr(w_ih_pk), L_.ptr(w_hh_pk), L_.ptr(bias),
+                    L_.ptr(lengths), L_.ptr(gates), L_.ptr(c_all), L_.ptr(h_all), L_.ptr(h_final),
+                    L, B, I_l, H, nd, float(in_drop[0]), int(in_drop[1]), L_.stream(), label=f'lstm_fwd_fused_I{I_l // H}',
+                    flops=2.0 * nd * L * B * 4 * H * (I_l + H))
+            saved += [gates, c_all, h_all]
+            inp, I_l = h_all, nd * H
+        ctx.save_for_backward(x, lengths, *saved, *weights)
+        ctx.dims = (L, B, H, nd)
+        ctx.drop = drop
+        ctx.x_act_slope = x_act_slope
+        ctx.consumed = False
+        return h_final
+
+    @staticmethod
+    def backward(ctx, dh_final):
+        if ctx.consumed:
+            raise L_.GmtError('this LSTM stack was already back-propagated: its saved gate buffers now hold '
+                              'd(pre-activation) (in-place backward); run the forward again instead of retain_graph')
+        if torch.is_grad_enabled():
+            raise NotImplementedError('LSTMStack2Fn: first-order backward only (the penalty pass uses LSTMLayerGPFn)')
+        ctx.consumed = True
+        x, lengths, g0, c0, h0, g1, c1, h1, *weights = ctx.saved_tensors
+        L, B, H, nd = ctx.dims
+        drop = ctx.drop
+        w0, w1 = weights[:4 * nd], weights[4 * nd:]
+        w_ih0, w_hh0 = [w0[4 * d] for d in range(nd)], [w0[4 * d + 1] for d in range(nd)]
+        w_ih1, w_hh1 = [w1[4 * d] for d in range(nd)], [w1[4 * d + 1] for d in range(nd)]
+        R, I1 = L * B, nd * H
+        dh_final = dh_final.contiguous()
+        need_w = any(ctx.needs_input_grad[4:])
+        # ---- top layer: sweep + input gradient in one launch
+        w_hh1_pkT = derived('hh_pkT', w_hh1, lambda: pack_transposed(w_hh1, H, 4 * H))
+        # W_ih as the B operand of dx = da W_ih with K = 4H in the LDS tile's gate-major order: the weight as it is
+        w_ih1_fx = derived('ih_fx_pk', w_ih1, lambda: torch.stack(
+            [_pack1(w, 4 * H, 4 * H, 1 << 30, 4, I1 // 128, 128, I1, 1) for w in w_ih1]))
+        dxp = torch.empty(R, I1, 2, device=x.device, dtype=torch.float32)
+        L_.call('gmt_lstm_layer_bwd_fx', L_.ptr(g1), L_.ptr(c1), L_.ptr(w_hh1_pkT), L_.ptr(lengths), None, L_.ptr(dh_final),
+                L_.ptr(w_ih1_fx), L_.ptr(dxp), L, B, H, I1, nd, 0.0, 0, L_.stream(), label='lstm_bwd_fx',
+                flops=2.0 * nd * R * 4 * H * (H + I1))
+        grads1 = _lstm_weight_grads(g1, h0.view(R, I1), h1, w_hh1, L, B, H, nd, drop) if need_w else [None] * (4 * nd)
+        # ---- bottom layer: reads the pairs (through the inter-layer dropout mask)
+        w_hh0_pkT = derived('hh_pkT', w_hh0, lambda: pack_transposed(w_hh0, H, 4 * H))
+        L_.call('gmt_lstm_layer_bwd_fx', L_.ptr(g0), L_.ptr(c0), L_.ptr(w_hh0_pkT), L_.ptr(lengths), L_.ptr(dxp), None,
+                None, None, L, B, H, H, nd, float(drop[0]), int(drop[1]), L_.stream(), label='lstm_bwd',
+                flops=2.0 * nd * R * 4 * H * H)
+        x2 = x.view(R, H)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            act = x2 if ctx.x_act_slope >= 0 else None
+            dx = dx_from_da(g0, w_ih0, R, act, max(ctx.x_act_slope, 0.0)).view(L, B, H)
+        grads0 = _lstm_weight_grads(g0, x2, h0, w_hh0, L, B, H, nd) if need_w else [None] * (4 * nd)
+        return (dx, None, None, None, *grads0, *grads1)
+
+
+def lstm_stack2(x, lengths_i32, w0, w1, drop: Tuple[float, int] = (0.0, 0), x_act_slope: float = -1.0):
+    return LSTMStack2Fn.apply(x, lengths_i32, drop, x_act_slope, *w0, *w1)
+
+
 def _lstm_weight_grads(da, x2, h_all, w_hh, L, B, H, nd, x_drop=(0.0, 0)):
     """dW_ih, dW_hh, db per direction from d(pre-activation) [nd,L,B,4H] (one contraction each)."""
     grads = []

@@ -256,6 +256,21 @@ int gmt_lstm_layer_bwd(float* gates, const float* c_all, const float* w_hh_pkT, 
                        int L, int B, int H, int ndir, float dy_dropout_p, unsigned dy_dropout_seed,
                        hipStream_t stream);
 
+/* gmt_lstm_layer_bwd_fx (H = 128): the plain backward sweep of a two-layer stack with the top layer's INPUT gradient
+ * contracted inside its time loop (what autograd computes for the input of layer 1 of torch.nn.LSTM, RG.py:772, in
+ * RG.py:1021 / 1109).  Called twice:
+ *   producer (top layer): dx_pairs given, dh_pairs NULL, dh_final = the adjoint of the final states, I = 2H;
+ *     w_ih_pkT = per direction gmt_pack_weight of W_ih [4H][I] as it is (K = 4H gate-major, 4 waves, I / 128 gates,
+ *     gate_stride 128, stride_k I, stride_n 1); dx_pairs [L*B][I][2]: slot d = direction d's partial dx (steps beyond a
+ *     tile's longest row are zeroed);
+ *   consumer (layer below): dh_pairs = that buffer (its two slots are added at use, through the inter-layer dropout mask
+ *     when dy_dropout_p > 0), dx_pairs NULL.
+ * Otherwise as gmt_lstm_layer_bwd: gates are overwritten in place by d(pre-activation). */
+int gmt_lstm_layer_bwd_fx(float* gates, const float* c_all, const float* w_hh_pkT, const int* lengths,
+                          const float* dh_pairs, const float* dh_final, const float* w_ih_pkT, float* dx_pairs,
+                          int L, int B, int H, int I, int ndir, float dy_dropout_p, unsigned dy_dropout_seed,
+                          hipStream_t stream);
+
 /* gmt_lstm_layer_bwd2: adjoint of gmt_lstm_layer_bwd itself - the LSTM part of
  * torch.autograd.grad(..., create_graph=True) in compute_gradient_penalty, RG.py:829-835.
  * In: xhat [L][B][I] = adjoint of dX, the forward-packed weights, the saved gates / c_all
