@@ -95,11 +95,19 @@ void dx_gemm_kernel(const float* __restrict__ dA, const float* __restrict__ w_pk
 // The hot shapes (N a multiple of 128, K <= 512: the H = 128 layers and the encoder) keep their weight block
 // RESIDENT: a workgroup owns one 128-column block of one direction's W at a time - 4 waves x 32 columns x K rows =
 // K/2 VGPRs a lane, loaded once per pass - and walks its tiles with nothing but dA flowing: global -> registers
-// (one float4 ahead of each group of MFMAs) -> LDS (transposed, double-buffered, written between the MFMAs of the
-// previous tile) -> MFMA A operand.  No weight traffic and no vmcnt stall inside a tile.  Directions are PASSES of
-// the same workgroup over the same tiles: pass d > 0 starts its accumulators from the partial dX the workgroup
-// itself stored in pass d - 1 (prefetched a tile ahead), so there is still one launch and no cross-workgroup
-// dependency.  One wave per SIMD (the weights fill the register file), like lstm_bwd_kernel.
+// (one float4 ahead of each group of MFMAs) -> LDS (double-buffered, written between the MFMAs of the previous tile)
+// -> MFMA.  No weight traffic and no vmcnt stall inside a tile.  Directions are PASSES of the same workgroup over the
+// same tiles: pass d > 0 starts its accumulators from the partial dX the workgroup itself stored in pass d - 1
+// (prefetched a tile ahead), so there is still one launch and no cross-workgroup dependency.  One wave per SIMD (the
+// weights fill the register file), like lstm_bwd_kernel.
+//
+// Round 3: the WEIGHTS are the MFMA's A operand (A[m = output column][k] - the same register contents as the B fragment
+// B[k][n] of the other form) and the dA tile its B operand, B[k][n = row]: the contraction yields dX TRANSPOSED in the
+// accumulators, lane = row, four consecutive registers = four consecutive output columns.  What that buys with one wave
+// per SIMD, where every issue slot shows: the tile sits in LDS ROW-major (pitch K + 2 floats: the 64 lanes of an operand
+// read - 32 rows x 2 k - fall into 64 different banks), so staging is two ds_write_b64 per float4 instead of four
+// transposing scalar writes; the epilogue's stores, the partial sums of the previous pass and the activation values
+// move as float4 (4 instead of 16 vector-memory instructions each per tile).
 template <int K, int N>
 __global__ __launch_bounds__(256, 1)
 void dx_gemm_res_kernel(const float* __restrict__ dA, const float* __restrict__ w_pk, float* __restrict__ dX,
@@ -107,11 +115,13 @@ void dx_gemm_res_kernel(const float* __restrict__ dA, const float* __restrict__ 
 {
     constexpr int NT = 256, KS = K / 2, KQ = K / 4;
     constexpr int XS = (GMT_TM * KQ) / NT;              // float4 of dA per thread and tile (K = 512: 16)
-    constexpr int NGRP = KS / 8;                        // MFMA groups per tile (gmt_mma_resident, one-gate form)
+    constexpr int NGRP = KS / 8;                        // MFMA groups per tile (8 k-steps each)
     constexpr int HALF = NGRP / 2;
+    constexpr int LDR = K + 2;                          // LDS row pitch (floats)
     static_assert(XS <= HALF, "one staged float4 per group");
+    static_assert(NT % KQ == 0, "staging map: whole rows per pass of the threads");
     constexpr int n_nb = N / 128;
-    extern __shared__ float smem[];                     // [2][K][LDA]
+    extern __shared__ float smem[];                     // [2][32][LDR]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lo = lane & 31;
@@ -127,12 +137,11 @@ void dx_gemm_res_kernel(const float* __restrict__ dA, const float* __restrict__ 
     const long long last_tile = worker + ((n_tiles - 1 - worker) / workers) * workers;   // this worker's final tile
     // addressing: one uniform base per tile (scalar registers) + ONE per-lane offset per buffer, laundered at each use
     // so that `offset + constant` is recomputed instead of being kept in a register per constant
-    const unsigned c_off = (unsigned)(4 * hi * N + nb * 128 + wave * 32 + lo);           // within a tile of dX / act
-    const unsigned s_off = (unsigned)((4 * (tid % KQ)) * GMT_LDA + tid / KQ);            // within an LDS buffer
-    static_assert(NT % KQ == 0 || KQ % NT == 0, "staging map");
+    const unsigned c_off = (unsigned)(lo * N + nb * 128 + wave * 32 + 4 * hi);            // within a tile of dX / act: row lo, + 8 q
+    const unsigned s_off = (unsigned)((tid / KQ) * LDR + 4 * (tid % KQ));                 // within an LDS buffer
 
     float4 xs[XS];
-    float cin[16], actv[16];
+    float4 cin[4], actv[4];
     for (int d = 0; d < ndir; ++d) {
         float wr[1][KS];
         gmt_load_resident<1, KS>(wr, reinterpret_cast<const float4*>(w_pk) + ((size_t)d * (N / 32) + nb * 4 + wave) * (K / 8) * 64, lane);
@@ -143,9 +152,10 @@ void dx_gemm_res_kernel(const float* __restrict__ dA, const float* __restrict__ 
             xs[j] = src[tid];
         };
         auto a_store1 = [&](float* buf, int j) {
-            // item tid + j NT: row (tid + j NT) / KQ, float4 column (tid + j NT) % KQ
-            float* p = buf + gmt_opaque_u(s_off) + (NT >= KQ ? j * (NT / KQ) : (4 * ((j * NT) % KQ)) * GMT_LDA + (j * NT) / KQ);
-            p[0] = xs[j].x; p[GMT_LDA] = xs[j].y; p[2 * GMT_LDA] = xs[j].z; p[3 * GMT_LDA] = xs[j].w;
+            // item tid + j NT: row (tid + j NT) / KQ, float4 column (tid + j NT) % KQ; rows are 8-byte aligned
+            float2* p = reinterpret_cast<float2*>(buf + gmt_opaque_u(s_off) + j * (NT / KQ) * LDR);
+            p[0] = make_float2(xs[j].x, xs[j].y);
+            p[1] = make_float2(xs[j].z, xs[j].w);
         };
         // prologue: tile 0 -> LDS[0], tile 1 -> registers, partial sums of tile 0
         long long tile = worker;
@@ -161,22 +171,34 @@ void dx_gemm_res_kernel(const float* __restrict__ dA, const float* __restrict__ 
         {
             const float* cb = dX + (size_t)tile * GMT_TM * N;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cin[r] = first ? 0.f : cb[c_off + ((r & 3) + 8 * (r >> 2)) * N];
+            for (int q = 0; q < 4; ++q) cin[q] = first ? make_float4(0.f, 0.f, 0.f, 0.f) : gmt_ld4(cb + c_off + 8 * q);
         }
         __syncthreads();
         int cur = 0;
         for (; tile <= last_tile; tile += workers) {
             const long long t1 = tile + workers <= last_tile ? tile + workers : last_tile;
             const long long t2 = t1 + workers <= last_tile ? t1 + workers : last_tile;
-            float* a_cur = smem + (size_t)cur * K * GMT_LDA;
-            float* a_nxt = smem + (size_t)(cur ^ 1) * K * GMT_LDA;
-            f32x16 acc[1];
+            const float* a_cur = smem + (size_t)cur * GMT_TM * LDR;
+            float* a_nxt = smem + (size_t)(cur ^ 1) * GMT_TM * LDR;
+            // accumulator register r = 4 q + e holds dX[row lo][column 8 q + 4 hi + e] of this wave's 32 columns
+            f32x16 acc, alt;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = cin[r];
+            for (int q = 0; q < 4; ++q) { acc[4 * q] = cin[q].x; acc[4 * q + 1] = cin[q].y; acc[4 * q + 2] = cin[q].z; acc[4 * q + 3] = cin[q].w; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) alt[r] = 0.f;
             float* c0 = dX + (size_t)tile * GMT_TM * N;                // uniform bases
             const float* c1 = dX + (size_t)t1 * GMT_TM * N;
             const float* ab = act ? act + (size_t)tile * GMT_TM * N : dX;
-            gmt_mma_resident<1, KS>(acc, a_cur, wr, lane, nullptr, [&](int grp) {
+            const float* bp = a_cur + lo * LDR + hi;                   // B operand: dA[row lo][k = 2 ks + hi]
+            float b[2][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[0][j] = bp[2 * j];
+#pragma unroll
+            for (int grp = 0; grp < NGRP; ++grp) {
+                if (grp + 1 < NGRP) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[(grp + 1) & 1][j] = bp[2 * ((grp + 1) * 8 + j)];
+                }
                 // first half of the groups: tile t1 (in registers since the previous trip) -> the other LDS buffer,
                 // and this tile's activation values; second half: tile t2 -> registers, tile t1's partial sums
                 if (grp < HALF) {
@@ -185,8 +207,8 @@ void dx_gemm_res_kernel(const float* __restrict__ dA, const float* __restrict__ 
                         if ((j * HALF) / XS == grp) a_store1(a_nxt, j);
                     if (final && act) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if ((r * HALF) / 16 == grp) actv[r] = ab[gmt_opaque_u(c_off) + ((r & 3) + 8 * (r >> 2)) * N];
+                        for (int q = 0; q < 4; ++q)
+                            if ((q * HALF) / 4 == grp) actv[q] = gmt_ld4(ab + gmt_opaque_u(c_off) + 8 * q);
                     }
                 } else {
                     const int g2 = grp - HALF;
@@ -195,18 +217,29 @@ void dx_gemm_res_kernel(const float* __restrict__ dA, const float* __restrict__ 
                         if ((j * HALF) / XS == g2) a_load1(t2, j);
                     if (!first) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if ((r * HALF) / 16 == g2) cin[r] = c1[gmt_opaque_u(c_off) + ((r & 3) + 8 * (r >> 2)) * N];
+                        for (int q = 0; q < 4; ++q)
+                            if ((q * HALF) / 4 == g2) cin[q] = gmt_ld4(c1 + gmt_opaque_u(c_off) + 8 * q);
                     }
                 }
-            });
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j & 1) alt = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[0][grp * 8 + j], b[grp & 1][j], alt, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[0][grp * 8 + j], b[grp & 1][j], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             {
                 float* cw = c0 + gmt_opaque_u(c_off);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[0][r];
-                    if (final && act) v *= (actv[r] > 0.f) ? 1.f : slope;
-                    cw[((r & 3) + 8 * (r >> 2)) * N] = v;
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = make_float4(acc[4 * q] + alt[4 * q], acc[4 * q + 1] + alt[4 * q + 1],
+                                           acc[4 * q + 2] + alt[4 * q + 2], acc[4 * q + 3] + alt[4 * q + 3]);
+                    if (final && act) {
+                        v.x *= (actv[q].x > 0.f) ? 1.f : slope; v.y *= (actv[q].y > 0.f) ? 1.f : slope;
+                        v.z *= (actv[q].z > 0.f) ? 1.f : slope; v.w *= (actv[q].w > 0.f) ? 1.f : slope;
+                    }
+                    *reinterpret_cast<float4*>(cw + 8 * q) = v;
                 }
             }
             __syncthreads();                            // every wave is done reading a_cur and writing a_nxt
@@ -219,7 +252,7 @@ template <int K, int N>
 int launch_dx_res(const float* dA, const float* w_pk, float* dX, const float* act, float slope, long long R,
                   int ndir, hipStream_t stream)
 {
-    const size_t lds = (size_t)2 * K * GMT_LDA * sizeof(float);
+    const size_t lds = (size_t)2 * GMT_TM * (K + 2) * sizeof(float);
     auto k = dx_gemm_res_kernel<K, N>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GMT_ERR_HIP;
