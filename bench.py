@@ -336,11 +336,13 @@ def main():
     if args.warmup is None:
         args.warmup = 8
 
-    for kv in args.ops_set:
-        from generative_mouse_trajectories_amd import ops as _ops
+    for kv in args.ops_set:                                    # NAME=V (ops) or ops_bf16.NAME=V
+        import importlib
         k, v = kv.split('=')
-        assert hasattr(_ops, k), k
-        setattr(_ops, k, type(getattr(_ops, k))(int(v)))
+        mod, _, k = k.rpartition('.')
+        _m = importlib.import_module('generative_mouse_trajectories_amd.' + (mod or 'ops'))
+        assert hasattr(_m, k), k
+        setattr(_m, k, type(getattr(_m, k))(int(v)))
     if args.no_mlp_kernels:
         from generative_mouse_trajectories_amd import ops as _ops
         _ops.MLP_KERNELS = False

@@ -222,6 +222,27 @@ def call(name, *args, label=None, flops=0.0, nbytes=0.0):
         raise GmtError(f'{name} failed: {ERRORS.get(rc, rc)}')
 
 
+class timed:
+    """`with timed(label, flops=...)`: the same per-label event timing as call() for work that is not one of the library's
+    entry points (a plain GEMM handed to hipBLASLt through torch)."""
+
+    def __init__(self, label, flops=0.0, nbytes=0.0):
+        self.label, self.flops, self.nbytes, self.a = label, float(flops), float(nbytes), None
+
+    def __enter__(self):
+        if PROFILE is not None and (PROFILE_ONLY is None or self.label in PROFILE_ONLY):
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.a is not None and PROFILE is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            PROFILE.setdefault(self.label, []).append((self.a, b, self.flops, self.nbytes))
+        return False
+
+
 def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

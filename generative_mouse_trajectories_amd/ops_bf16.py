@@ -19,6 +19,7 @@ from __future__ import annotations
 from typing import List, Optional
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib as L_
 from . import ops
@@ -92,6 +93,16 @@ def slab_unperm_rows(w: torch.Tensor, H: int) -> torch.Tensor:
     return out
 
 
+# The PLAIN hoisted GEMMs (no activation epilogue: the layers' input projections x W_ih^T + b and the input gradients
+# dA W_ih over all L*B row-steps) go to the library GEMM torch dispatches to (hipBLASLt): measured on the config-3 shapes
+# (tools/bench_bf16_gemm_vs_lib.py, M = 1.05 M rows): N4096 K512 763 -> 835 TF/s, N4096 K1024 953 -> 1262, N1024 K4096
+# 1101 -> 1445, N512 K4096 1024 -> 1340.  GEMMs with a fused LeakyReLU / x LeakyReLU' epilogue stay on gmt_bf16_gemm_nt
+# (a separate element-wise pass over [M, N] would cost more than the library gains).  The library adds the bias in bf16
+# (one rounding of the bias more than the kernel's fp32 add: inside the bf16 path's tolerances).  False: everything on
+# the hand-written kernel (A/B switch).
+LIBRARY_PLAIN_GEMM = True
+
+
 def gemm_nt(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[torch.Tensor] = None,
             epilogue: int = 0, slope: float = 0.2, label: Optional[str] = None) -> torch.Tensor:
     """C = epilogue(A W^T + bias): A [M, K] bf16 (row stride >= K), W [N, K] bf16 -> [M, N] bf16."""
@@ -100,6 +111,9 @@ def gemm_nt(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = Non
     L_.require_cuda(A, W)
     assert A.dtype == BF16 and W.dtype == BF16 and A.stride(1) == 1 and W.stride(1) == 1 and W.shape[1] == K
     assert act is None or (act.dtype == BF16 and act.stride(1) == 1 and act.shape == (M, N))
+    if LIBRARY_PLAIN_GEMM and epilogue == 0 and act is None and A.is_contiguous() and W.is_contiguous():
+        with L_.timed(label or f'bf16_gemm_N{N}_K{K}', flops=2.0 * M * N * K):
+            return F.linear(A, W, None if bias is None else bias.to(BF16))
     C = torch.empty(M, N, device=A.device, dtype=BF16)
     L_.call('gmt_bf16_gemm_nt', A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), L_.ptr(C), N,
             L_.ptr(bias) if bias is not None else None, act.data_ptr() if act is not None else None,
