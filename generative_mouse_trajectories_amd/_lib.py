@@ -75,7 +75,8 @@ class CondBwdArgs(ctypes.Structure):
 
 class HeadFwdArgs(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ('x', 'w1', 'b1', 'w2', 'b2', 'w3', 'b3', 'score', 'a1', 'a2')] \
-        + [(n, c_i) for n in ('Bp', 'H', 'a2_pitch')] + [('slope', c_f), ('dropout_p', c_f), ('seed', ctypes.c_uint)]
+        + [(n, c_i) for n in ('Bp', 'H', 'a2_pitch')] + [('slope', c_f), ('dropout_p', c_f), ('seed', ctypes.c_uint)] \
+        + [('m1', c_p), ('m2', c_p)]
 
 
 class HeadBwdArgs(ctypes.Structure):

@@ -37,15 +37,17 @@ def kinematics_torch(pos: torch.Tensor, dts: torch.Tensor, eps: float = 1e-8) ->
                         jerk.clamp(-10000, 10000), curv.clamp(0, 100)], dim=-1)
 
 
+GP_KERNEL_HEAD = True           # False: the critic head of the penalty pass as torch ops (A/B switch)
 GP_KERNEL_FRONT_END = True      # False: the torch-composite front end (kept for widths the kernels do not cover, and as an A/B switch)
 
 
 def discriminator_forward_gp(D, trajectories: torch.Tensor, dts: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
     """Twice-differentiable discriminator forward for the gradient penalty: the BiLSTM runs in
     the HIP kernels (ops.LSTMLayerGPFn: forward, first backward and the second-order sweep
-    are each one persistent launch per layer); the cheap non-recurrent pieces (kinematic
-    features, the Linear layers) are torch ops, which autograd differentiates twice; the spectral-norm
-    weights come from gmt_spectral_norm_fwd and are only differentiated once (they do not depend on the input)."""
+    are each one persistent launch per layer), and so do the front end (ops.EncoderGPFn) and the
+    output head (ops.CriticHeadGPFn) when their widths are in the kernels' tables - torch ops otherwise, which autograd
+    differentiates twice; the spectral-norm weights come from gmt_spectral_norm_fwd and are only differentiated once (they
+    do not depend on the input)."""
     from . import ops
     from .models import _pad_batch
     L_.require_cuda(trajectories, dts)
@@ -77,11 +79,27 @@ def discriminator_forward_gp(D, trajectories: torch.Tensor, dts: torch.Tensor, l
         lw = [w for l in range(nl) for w in D.lstm.layer_weights(l)]
         drop_p = cfg.lstm_dropout if (D.training and nl > 1) else 0.0
         h_final = ops_bf16.lstm_stack_gp(x.contiguous(), nl, lw, lens, drop_p)
-        return D.run_sequential(D.output_layers, h_final[:B], sn_w)
+        return _gp_head(D, h_final, sn_w, B)
     h_final = None
     for l in range(nl):
         h_all, h_final, _, _ = ops.LSTMLayerGPFn.apply(x.contiguous(), lens, *D.lstm.layer_weights(l))
         x = h_all
         if l + 1 < nl and D.training and cfg.lstm_dropout > 0:
             x = F.dropout(x, cfg.lstm_dropout, True)
+    return _gp_head(D, h_final, sn_w, B)
+
+
+def _gp_head(D, h_final: torch.Tensor, sn_w, B: int) -> torch.Tensor:
+    """output_layers on the (padded) final states of the penalty pass -> scores of the B valid rows."""
+    from . import ops
+    ol = D.output_layers
+    H = D.config.discriminator_hidden_dim
+    if (GP_KERNEL_HEAD and ops.critic_head_supported(H) and len(ol) == 6 and len(sn_w) == 3 and h_final.dtype == torch.float32
+            and h_final.shape[0] % ops.TM == 0 and ol[1].negative_slope == ol[4].negative_slope):
+        # the 3-Linear head in kernels too, twice differentiable (ops.CriticHeadGPFn / CriticHeadBwdGPFn); its Dropout is
+        # the counter-based mask of the ordinary critic call, drawn per call
+        p = float(ol[2].p) if D.training else 0.0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
+        w1, w2, w3 = sn_w
+        return ops.critic_head_gp(h_final, w1, ol[0].bias, w2, ol[3].bias, w3, ol[5].bias, float(ol[1].negative_slope), p, seed)[:B]
     return D.run_sequential(D.output_layers, h_final[:B], sn_w)

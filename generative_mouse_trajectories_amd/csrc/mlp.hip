@@ -364,10 +364,14 @@ void head_fwd_kernel(const gmt_head_fwd_args p)
     const uint32_t thresh24 = (uint32_t)(p.dropout_p * 16777216.0f);
     const float keep_scale = 1.0f / (1.0f - p.dropout_p);
 
+    // mask mode (p.m1 given): the adjoint of the head's backward pass - the same three contractions with the saved
+    // activations' LeakyReLU' / dropout factors in place of the non-linearities and no biases (second backward of the
+    // gradient penalty, RG.py:829-835)
+    const bool mm = p.m1 != nullptr;
     // ---- Linear(2H -> H) + LeakyReLU + Dropout
     {
         f32x16 acc[1];
-        const float bv = p.b1[col];
+        const float bv = mm ? 0.f : p.b1[col];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = bv;
         for (int c0 = 0; c0 < 2 * H; c0 += CH) {
@@ -385,7 +389,7 @@ void head_fwd_kernel(const gmt_head_fwd_args p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = gmt_acc_row(r, lane);
-            float v = mlp_lrelu(acc[0][r], p.slope);
+            float v = mm ? acc[0][r] * (p.m1[(size_t)(row0 + row) * H + col] > 0.f ? 1.0f : p.slope) : mlp_lrelu(acc[0][r], p.slope);
             if (thresh24) v = gmt_keep((uint32_t)(row0 + row) * (uint32_t)H + (uint32_t)col, p.seed, thresh24) ? v * keep_scale : 0.f;
             a1b[row * LD + col] = v;
             if (p.a1) p.a1[(size_t)(row0 + row) * H + col] = v;
@@ -396,7 +400,7 @@ void head_fwd_kernel(const gmt_head_fwd_args p)
     if (32 * wave < N2) {
         const bool in = col < N2;
         f32x16 acc[1];
-        const float bv = in ? p.b2[col] : 0.f;
+        const float bv = (in && !mm) ? p.b2[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = bv;
         const float* const wrow[1] = {p.w2 + (size_t)(in ? col : N2 - 1) * H};
@@ -405,7 +409,8 @@ void head_fwd_kernel(const gmt_head_fwd_args p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = gmt_acc_row(r, lane);
-                const float v = mlp_lrelu(acc[0][r], p.slope);
+                const float v = mm ? acc[0][r] * (p.m2[(size_t)(row0 + row) * p.a2_pitch + col] > 0.f ? 1.0f : p.slope)
+                                   : mlp_lrelu(acc[0][r], p.slope);
                 a2b[row * LD2 + col] = v;
                 if (p.a2) p.a2[(size_t)(row0 + row) * p.a2_pitch + col] = v;
             }
@@ -418,7 +423,7 @@ void head_fwd_kernel(const gmt_head_fwd_args p)
     __syncthreads();
     // ---- Linear(H/2 -> 1)
     if (tid < 32) {
-        float s = p.b3[0];
+        float s = mm ? 0.f : p.b3[0];
 #pragma unroll 8
         for (int j = 0; j < N2; ++j) s += a2b[tid * LD2 + j] * p.w3[j];
         p.score[row0 + tid] = s;
@@ -541,7 +546,9 @@ extern "C" int gmt_cond_encoder_bwd(const gmt_cond_bwd_args* a, hipStream_t stre
 
 extern "C" int gmt_critic_head_fwd(const gmt_head_fwd_args* a, hipStream_t stream)
 {
-    GMT_CHECK_ARG(a && a->x && a->w1 && a->b1 && a->w2 && a->b2 && a->w3 && a->b3 && a->score && al16(a->x));
+    GMT_CHECK_ARG(a && a->x && a->w1 && a->w2 && a->w3 && a->score && al16(a->x));
+    GMT_CHECK_ARG((a->m1 != nullptr) == (a->m2 != nullptr));
+    GMT_CHECK_ARG(a->m1 || (a->b1 && a->b2 && a->b3));
     GMT_CHECK_ARG(a->Bp >= 32 && (a->Bp % 32) == 0 && a->dropout_p >= 0.f && a->dropout_p < 1.f);
     GMT_CHECK_ARG(!a->a2 || a->a2_pitch >= a->H / 2);
     GMT_CHECK_ARG((long long)a->Bp * a->H < (1ll << 32));              // 32-bit dropout counter

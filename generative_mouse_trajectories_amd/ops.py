@@ -1222,6 +1222,122 @@ class CriticHeadFn(torch.autograd.Function):
         return dx, d_w1, d_b1, d_w2, d_b2, d_w3[:1], d_b3[:1], None, None, None
 
 
+def _head_fwd_launch(x, w1, b1, w2, b2, w3, b3, slope, p, seed, a1, a2, a2p, m1=None, m2=None, label='critic_head_fwd'):
+    Bp, H2 = x.shape
+    H = H2 // 2
+    score = torch.empty(Bp, 1, device=x.device, dtype=torch.float32)
+    a = L_.HeadFwdArgs()
+    a.x = x.data_ptr()
+    a.w1, a.w2, a.w3 = w1.data_ptr(), w2.data_ptr(), w3.data_ptr()
+    a.b1, a.b2, a.b3 = L_.ptr(b1), L_.ptr(b2), L_.ptr(b3)
+    a.score, a.a1, a.a2 = score.data_ptr(), L_.ptr(a1), L_.ptr(a2)
+    a.m1, a.m2 = L_.ptr(m1), L_.ptr(m2)
+    a.Bp, a.H, a.a2_pitch = Bp, H, a2p
+    a.slope, a.dropout_p, a.seed = float(slope), float(p), int(seed) & 0xFFFFFFFF
+    L_.call('gmt_critic_head_fwd', ctypes_byref(a), L_.stream(), label=label, flops=2.0 * Bp * (H2 * H + H * (H // 2) + H // 2))
+    return score
+
+
+class CriticHeadBwdGPFn(torch.autograd.Function):
+    """The head's first backward as a differentiable function of the score adjoint and the three weights (the saved
+    activations only enter through LeakyReLU' / dropout factors, which are piecewise constant):
+    (d_score [Bp,1], w1, w2, w3, a1, a2, meta) -> dx [Bp,2H] = ((d_score w3 * f2) W2 * f1) W1   (gmt_critic_head_bwd).
+    Its backward - the head's piece of the penalty's second backward (RG.py:829-835) - is the head forward kernel in
+    mask mode for the adjoint of d_score plus three contractions on gmt_wgrad for the adjoints of the weights."""
+
+    @staticmethod
+    def forward(ctx, d_score, w1, w2, w3, a1, a2, meta):
+        Bp, H, a2p, slope, p, seed = meta
+        N2 = H // 2
+        dev = a1.device
+        f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+        ds = d_score.detach().contiguous()
+        w1c, w2c, w3c = w1.detach().contiguous(), w2.detach().contiguous(), w3.detach().contiguous()
+        dx, dy1, dy2, ds4 = f(Bp, 2 * H), f(Bp, H), f(Bp, N2), f(Bp, 4)
+        a = L_.HeadBwdArgs()
+        a.d_score, a.a1, a.a2 = ds.data_ptr(), a1.data_ptr(), a2.data_ptr()
+        a.w1, a.w2, a.w3 = w1c.data_ptr(), w2c.data_ptr(), w3c.data_ptr()
+        a.dx, a.dy1, a.dy2, a.ds4 = dx.data_ptr(), dy1.data_ptr(), dy2.data_ptr(), ds4.data_ptr()
+        a.Bp, a.H, a.a2_pitch, a.slope, a.dropout_p, a.seed = Bp, H, a2p, slope, p, seed
+        L_.call('gmt_critic_head_bwd', ctypes_byref(a), L_.stream(), label='critic_head_bwd',
+                flops=2.0 * Bp * (2 * H * H + H * N2 + N2))
+        ctx.save_for_backward(w1c, w2c, w3c, a1, a2, dy1, dy2, ds4)
+        ctx.meta = meta
+        return dx
+
+    @staticmethod
+    def backward(ctx, xhat):
+        if torch.is_grad_enabled():
+            raise NotImplementedError('CriticHeadBwdGPFn: differentiable once (the penalty needs no third derivative)')
+        w1, w2, w3, a1, a2, dy1, dy2, ds4 = ctx.saved_tensors
+        Bp, H, a2p, slope, p, seed = ctx.meta
+        N2 = H // 2
+        dev = a1.device
+        xh = xhat.contiguous()
+        u1 = torch.empty(Bp, H, device=dev, dtype=torch.float32)
+        u2 = torch.empty(Bp, a2p, device=dev, dtype=torch.float32)
+        dds = _head_fwd_launch(xh, w1, None, w2, None, w3, None, slope, p, seed, u1, u2, a2p, a1, a2, label='critic_head_bwd2')
+        d_w1 = d_w2 = d_w3 = None
+        if ctx.needs_input_grad[1]:
+            d_w1 = wgrad(dy1, xh)[0]
+        if ctx.needs_input_grad[2]:
+            d_w2 = wgrad(dy2, u1)[0]
+        if ctx.needs_input_grad[3]:
+            d_w3 = wgrad(ds4, u2[:, :N2], x_padded=a2p != N2)[0][:1]
+        return (dds if ctx.needs_input_grad[0] else None), d_w1, d_w2, d_w3, None, None, None
+
+
+class CriticHeadGPFn(torch.autograd.Function):
+    """CriticHeadFn for the gradient-penalty pass: same forward launch; under create_graph=True its backward hands the
+    input gradient over as CriticHeadBwdGPFn (differentiable once more); called without a graph it is CriticHeadFn's."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, slope, p, seed):
+        L_.require_cuda(x, w1)
+        Bp, H2 = x.shape
+        H, N2 = H2 // 2, H2 // 4
+        assert Bp % TM == 0 and w1.shape == (H, H2) and w2.shape == (N2, H) and w3.shape == (1, N2)
+        f = lambda *sh: torch.empty(*sh, device=x.device, dtype=torch.float32)
+        xc = x.detach().contiguous()
+        ws = [t.detach().contiguous() for t in (w1, b1, w2, b2, w3, b3)]
+        a2p = _pitch128(N2)
+        a1, a2 = f(Bp, H), f(Bp, a2p)
+        score = _head_fwd_launch(xc, ws[0], ws[1], ws[2], ws[3], ws[4], ws[5], slope, p, seed, a1, a2, a2p)
+        ctx.save_for_backward(xc, w1, w2, w3, a1, a2)
+        ctx.meta = (Bp, H, a2p, float(slope), float(p), int(seed) & 0xFFFFFFFF)
+        return score
+
+    @staticmethod
+    def backward(ctx, d_score):
+        x, w1, w2, w3, a1, a2 = ctx.saved_tensors
+        meta = ctx.meta
+        Bp, H, a2p, slope, p, seed = meta
+        N2 = H // 2
+        if torch.is_grad_enabled():
+            # the penalty's inner autograd.grad: only the input gradient is asked for (RG.py:829-835)
+            dx = CriticHeadBwdGPFn.apply(d_score, w1, w2, w3, a1, a2, meta)
+            return dx, None, None, None, None, None, None, None, None, None
+        ds = d_score.contiguous()
+        f = lambda *sh: torch.empty(*sh, device=x.device, dtype=torch.float32)
+        w1c, w2c, w3c = w1.detach().contiguous(), w2.detach().contiguous(), w3.detach().contiguous()
+        dx, dy1, dy2, ds4 = f(Bp, 2 * H), f(Bp, H), f(Bp, N2), f(Bp, 4)
+        a = L_.HeadBwdArgs()
+        a.d_score, a.a1, a.a2 = ds.data_ptr(), a1.data_ptr(), a2.data_ptr()
+        a.w1, a.w2, a.w3 = w1c.data_ptr(), w2c.data_ptr(), w3c.data_ptr()
+        a.dx, a.dy1, a.dy2, a.ds4 = dx.data_ptr(), dy1.data_ptr(), dy2.data_ptr(), ds4.data_ptr()
+        a.Bp, a.H, a.a2_pitch, a.slope, a.dropout_p, a.seed = Bp, H, a2p, slope, p, seed
+        L_.call('gmt_critic_head_bwd', ctypes_byref(a), L_.stream(), label='critic_head_bwd',
+                flops=2.0 * Bp * (2 * H * H + H * N2 + N2))
+        d_w1, d_b1 = wgrad(dy1, x, want_db=True)
+        d_w2, d_b2 = wgrad(dy2, a1, want_db=True)
+        d_w3, d_b3 = wgrad(ds4, a2[:, :N2], want_db=True, x_padded=a2p != N2)
+        return dx, d_w1, d_b1, d_w2, d_b2, d_w3[:1], d_b3[:1], None, None, None
+
+
+def critic_head_gp(x, w1, b1, w2, b2, w3, b3, slope: float = 0.2, p: float = 0.0, seed: int = 0):
+    return CriticHeadGPFn.apply(x, w1, b1, w2, b2, w3, b3, slope, p, seed)
+
+
 def critic_head_supported(H: int) -> bool:
     return MLP_KERNELS and H in MLP_WIDTHS
 

@@ -402,6 +402,11 @@ typedef struct gmt_head_fwd_args {
     float* a2;              /* [Bp][a2_pitch] out: second activation, zero-padded to the pitch (saved), or NULL */
     int Bp, H, a2_pitch;
     float slope, dropout_p; unsigned int seed;
+    /* mask mode (both given, b1..b3 unused): m1 [Bp][H], m2 [Bp][a2_pitch] = the saved a1 / a2 of an earlier call; the
+     * LeakyReLUs are replaced by a multiplication with LeakyReLU'(m) (and the same dropout factor) and there are no
+     * biases: score = ((x W1^T * f1) W2^T * f2) w3^T, a1 / a2 receive the two intermediate products.  This is the adjoint
+     * of gmt_critic_head_bwd as a function of d_score - the head's piece of the penalty's second backward (RG.py:829-835). */
+    const float* m1; const float* m2;
 } gmt_head_fwd_args;
 int gmt_critic_head_fwd(const gmt_head_fwd_args* args, hipStream_t stream);
 

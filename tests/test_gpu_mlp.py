@@ -161,3 +161,38 @@ def test_discriminator_uses_the_head_kernel_and_matches_its_torch_composite():
     close(s1, s2, 2e-5, 'score')
     for k, p in D.named_parameters():
         close(g1[k], p.grad, 1e-4, f'grad {k}')
+
+
+@pytest.mark.parametrize('H,Bp,p', [(128, 64, 0.0), (128, 1024, 0.3), (32, 32, 0.3)])
+def test_critic_head_double_backward_vs_float64(H, Bp, p):
+    """The penalty's use of the head (RG.py:829-835): gradient of the score w.r.t. the input with create_graph=True, then the
+    gradient of a function of that gradient w.r.t. the three weights - ops.CriticHeadGPFn / CriticHeadBwdGPFn (head forward
+    kernel in mask mode + gmt_wgrad) against float64 torch autograd with the replayed dropout mask."""
+    from generative_mouse_trajectories_amd import ops
+    gen = torch.Generator().manual_seed(21 + H)
+    N2 = H // 2
+    x = torch.randn(Bp, 2 * H, generator=gen)
+    ws = [torch.randn(H, 2 * H, generator=gen) / (2 * H) ** 0.5, 0.1 * torch.randn(H, generator=gen),
+          torch.randn(N2, H, generator=gen) / H ** 0.5, 0.1 * torch.randn(N2, generator=gen),
+          torch.randn(1, N2, generator=gen) / N2 ** 0.5, 0.1 * torch.randn(1, generator=gen)]
+    seed = 99
+    mask = ops.dropout_keep_mask(1, Bp, H, p, seed).view(Bp, H).double() if p > 0 else None
+    tgt = torch.randn(Bp, 2 * H, generator=gen)
+
+    def penalty(score, xin, dev_tgt):
+        g, = torch.autograd.grad(score, xin, torch.ones_like(score), create_graph=True)
+        return ((g - 0.05 * dev_tgt) ** 2).sum(1).mean()
+
+    xd = x.to(DEV).requires_grad_(True)
+    wd = [w.to(DEV).requires_grad_(True) for w in ws]
+    pen = penalty(ops.critic_head_gp(xd, *wd, 0.2, p, seed), xd, tgt.to(DEV))
+    pen.backward()
+    x64 = x.double().requires_grad_(True)
+    w64 = [w.double().requires_grad_(True) for w in ws]
+    ref = penalty(head_reference(x64, *w64, 0.2, mask), x64, tgt.double())
+    ref.backward()
+    close(pen, ref, 2e-5, 'penalty')
+    for k in (0, 2, 4):                                      # the weights; biases do not enter the input gradient
+        close(wd[k].grad, w64[k].grad, 1e-4, f'second-order gradient of head weight {k}')
+    for k in (1, 3, 5):
+        assert wd[k].grad is None or float(wd[k].grad.abs().sum()) == 0.0
