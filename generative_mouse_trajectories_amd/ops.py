@@ -109,29 +109,48 @@ def weights_changed(params=None) -> None:
         del _DERIVED[key]
 
 
+def _record_stream(value, stream) -> None:
+    if isinstance(value, torch.Tensor):
+        if value.is_cuda:
+            value.record_stream(stream)
+    elif isinstance(value, (tuple, list)):
+        for v in value:
+            _record_stream(v, stream)
+
+
 def derived(kind: str, tensors, build):
     """build() -> derived tensor(s) of the PARAMETERS `tensors`, cached until those change.  An entry is valid only
     for the very same tensor objects (weak references: a new tensor that happens to get a dead one's address or
     id never matches), at the same autograd version (in-place torch updates bump it) and the same weights epoch
     (the fused Adam kernel and the load paths, which write behind autograd's back, call weights_changed()).
     Never pass temporaries (e.g. spectrally normalised weights, which are new tensors every call).
-    No stream is recorded with an entry: build() runs on the caller's current stream and later hits on ANOTHER stream
-    are only ordered after it if that stream was made to wait for the building one - so whoever uses a second stream
-    builds what that stream will read on the main stream first (Generator.prepack, called by the Trainer before it
-    forks) and forks afterwards."""
+    An entry remembers the stream build() ran on (an event recorded right after it): the first hit from ANOTHER stream
+    makes that stream wait for the event, so two streams may share the cache in either order (the critic's main-stream
+    calls and the gradient-penalty pass on the side stream; Generator.prepack still builds the rollout's packs up front)."""
     import weakref
     key = (kind,) + tuple(id(t) for t in tensors)
     hit = _DERIVED.get(key)
+    cur = torch.cuda.current_stream() if tensors[0].is_cuda else None
     if hit is not None:
-        refs, versions, epoch, value = hit
+        refs, versions, epoch, value, built = hit
         if epoch == _WEIGHTS_EPOCH and all(r() is t for r, t in zip(refs, tensors)) \
                 and versions == tuple(t._version for t in tensors):
+            if built is not None and cur is not None and cur.cuda_stream not in built[1]:
+                # first use on another stream than the one build() ran on: ordered behind the build, once
+                cur.wait_event(built[0])
+                built[1].add(cur.cuda_stream)
+                _record_stream(value, cur)           # (the allocator must not hand the block back to the building stream early)
             return value
     if len(_DERIVED) > 512:                          # parameters updated by plain torch optimizers: bounded
         _DERIVED.clear()
     with torch.no_grad():
         value = build()
-    _DERIVED[key] = (tuple(weakref.ref(t) for t in tensors), tuple(t._version for t in tensors), _WEIGHTS_EPOCH, value)
+    built = None
+    if cur is not None:
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        built = (ev, {cur.cuda_stream})
+    _DERIVED[key] = (tuple(weakref.ref(t) for t in tensors), tuple(t._version for t in tensors), _WEIGHTS_EPOCH, value, built)
     return value
 
 
