@@ -76,9 +76,28 @@ def test_bf16_rows_are_independent_and_match_the_oracle_at_config3_size():
         dpad = torch.nn.functional.pad(seq[:, :, 2], (1, 0), value=0.05).to(DEV)
         lp1 = (lengths + 1).to(DEV)
         state = {k: v.clone() for k, v in D.state_dict().items()}
+        # Bit-identity across batch sizes is a property of the hand-written kernels (same arithmetic per row whatever the tile
+        # grid).  The plain hoisted GEMMs go to the library by default (ops_bf16.LIBRARY_PLAIN_GEMM), whose summation order
+        # depends on M: asserted to the bit with the switch off, to 1e-2 of the scores' scale with it on (measured 1-3e-3:
+        # single bf16 roundings of pre-activations that flip).
+        from generative_mouse_trajectories_amd import ops_bf16 as OB
+        lib_default = OB.LIBRARY_PLAIN_GEMM
+        try:
+            OB.LIBRARY_PLAIN_GEMM = False
+            s_full = _critic_pass(D, state, real, dpad, lp1)
+            s_part = _critic_pass(D, state, real[sd], dpad[sd], lp1[sd])
+            assert torch.equal(s_full[sd], s_part), 'D scores: rows of the 4096-row batch vs the same rows as a 512-row batch'
+            OB.LIBRARY_PLAIN_GEMM = True
+            l_full = _critic_pass(D, state, real, dpad, lp1)
+            l_part = _critic_pass(D, state, real[sd], dpad[sd], lp1[sd])
+            scale = float(s_full.abs().max())
+            e_lib = float((l_full[sd] - l_part).abs().max()) / scale
+            e_own = float((l_full - s_full).abs().max()) / scale
+            print(f'library plain GEMMs: rows across batch sizes {e_lib:.1e}, against the own GEMM {e_own:.1e} (of the score scale)')
+            assert e_lib <= 1e-2 and e_own <= 1e-2, (e_lib, e_own)
+        finally:
+            OB.LIBRARY_PLAIN_GEMM = lib_default
         s_full = _critic_pass(D, state, real, dpad, lp1)
-        s_part = _critic_pass(D, state, real[sd], dpad[sd], lp1[sd])
-        assert torch.equal(s_full[sd], s_part), 'D scores: rows of the 4096-row batch vs the same rows as a 512-row batch'
         D.load_state_dict(state)
         head, D.output_layers = D.output_layers, torch.nn.Sequential()     # the body alone: the final hidden states (RG.py:776-778)
         h_full = D(real, dpad, lp1)
