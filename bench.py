@@ -349,6 +349,13 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > max(1, torch.cuda.device_count()) and not args.no_real_overlap:
+        # Rehearsal of N ranks on fewer GPUs (several processes on one card): the G step's real-forward overlap is left
+        # out.  Two processes that each run a half-machine BPTT kernel beside a full-machine persistent forward on a
+        # second stream stalled on a shared MI355X at the bench size (round 3: both ranks' queues stop, Python stacks in
+        # the host-staged all-reduce after the G step; `HIP_LAUNCH_BLOCKING=1` or this switch complete; one rank per GPU
+        # - also with an RCCL group - completes: DESIGN.md section 6).  One rank per GPU, the real launch, keeps it.
+        args.no_real_overlap = True
     local_rank %= max(1, torch.cuda.device_count())       # (rehearsing N ranks on a one-GPU box: they share the card)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)

@@ -1061,6 +1061,8 @@ def critic_loss(real_padded, fake_padded, B: int):
 # ----------------------------------------------------------------------------------------
 MLP_WIDTHS = (32, 64, 128, 256, 512)
 MLP_KERNELS = True       # False: condition encoder / critic head as torch ops (A/B switch, bench.py --no-mlp-kernels)
+MLP_COND = True          # the two halves of that switch
+MLP_HEAD = True
 
 
 def _pitch128(n: int) -> int:
@@ -1160,7 +1162,7 @@ class CondEncoderFn(torch.autograd.Function):
 
 def cond_encoder_supported(G) -> bool:
     ce = G.condition_encoder
-    return (MLP_KERNELS and G.config.generator_hidden_dim in MLP_WIDTHS and ce[2].negative_slope == ce[5].negative_slope
+    return (MLP_KERNELS and MLP_COND and G.config.generator_hidden_dim in MLP_WIDTHS and ce[2].negative_slope == ce[5].negative_slope
             and ce[1].eps == ce[4].eps and ce[0].weight.dtype == torch.float32)
 
 
@@ -1358,7 +1360,7 @@ def critic_head_gp(x, w1, b1, w2, b2, w3, b3, slope: float = 0.2, p: float = 0.0
 
 
 def critic_head_supported(H: int) -> bool:
-    return MLP_KERNELS and H in MLP_WIDTHS
+    return MLP_KERNELS and MLP_HEAD and H in MLP_WIDTHS
 
 
 def critic_head(x, w1, b1, w2, b2, w3, b3, slope: float = 0.2, p: float = 0.0, seed: int = 0):
