@@ -35,9 +35,9 @@ PEAK_HBM_GBS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (the headline 5 PF figure is 2:1 sparse)
 # HBM bytes per launch from the PMC passes under profiles/ (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3
 # runs): known only for the kernel / shape that was counted
-PMC_TRAFFIC_BYTES = {('lstm_fwd_fused_I2', 4096): (4.91e9, 'profiles/r3_06_pmc_hbm.txt'),
-                     ('lstm_bwd_fx', 4096): (7.85e9, 'profiles/r3_06_pmc_hbm.txt'),
-                     ('lstm_fwd_fused_I1', 4096): (3.95e9, 'profiles/r3_06_pmc_hbm.txt'),
+PMC_TRAFFIC_BYTES = {('lstm_fwd_fused_I2', 4096): (4.86e9, 'profiles/r3_08_pmc_hbm.txt'),
+                     ('lstm_bwd_fx', 4096): (7.85e9, 'profiles/r3_08_pmc_hbm.txt'),
+                     ('lstm_fwd_fused_I1', 4096): (3.95e9, 'profiles/r3_08_pmc_hbm.txt'),
                      # config 3: a labelled launch is a whole layer sweep of 257 step launches (183.6 MB read + 61.0 MB written each)
                      ('bf16_lstm_bwd', 4096): (257 * 244.6e6, 'profiles/r2_06_pmc_lstm_steps.txt: per step launch x 257'),
                      ('bf16_lstm_fwd', 4096): (257 * 147.9e6, 'profiles/r2_06_pmc_lstm_steps.txt: per step launch x 257')}
