@@ -109,8 +109,9 @@ class Generator(nn.Module):
         if self.bf16:
             if H != 512:
                 raise NotImplementedError('compute_dtype bf16: the generator rollout is built for generator_hidden_dim = 512')
-        elif H % 32 != 0 or H > 256:
-            raise NotImplementedError("generator_hidden_dim must be a multiple of 32, at most 256 (512: compute_dtype = 'bf16')")
+        elif H not in (32, 64, 128, 256):
+            raise NotImplementedError("generator_hidden_dim must be 32, 64, 128 or 256 - the widths the rollout kernels are "
+                                      "instantiated for (512: compute_dtype = 'bf16')")
         self.condition_encoder = nn.Sequential(
             nn.Linear(6 + config.latent_dim, H), nn.LayerNorm(H), nn.LeakyReLU(0.2),
             nn.Linear(H, H), nn.LayerNorm(H), nn.LeakyReLU(0.2))
@@ -154,7 +155,7 @@ class Generator(nn.Module):
             # condition features, both Linear / LayerNorm / LeakyReLU stages and the hoisted gate term in one launch, already
             # padded to Bp rows and in the unit-major column order of the rollout's gate buffers (csrc/mlp.hip)
             _, g0 = ops.cond_encoder(self, start, end, z, Bp, unit_major=True, want_g0=True)
-        else:                                            # widths outside the kernel's table (H not a power of two): torch ops
+        else:                                            # the A/B switch ops.MLP_COND off: torch ops
             cond = self._compute_condition(start, end, z)
             g0 = F.linear(cond, w_ih0[:, 3:3 + H], lp.bias_ih_l0 + lp.bias_hh_l0)
             g0 = _pad_batch(g0, Bp, 0)
@@ -308,8 +309,9 @@ class Discriminator(nn.Module):
         if self.bf16:
             if H % 256 != 0 or H > 1024:
                 raise NotImplementedError('compute_dtype bf16: discriminator_hidden_dim must be a multiple of 256, at most 1024')
-        elif H % 32 != 0 or H > 256:
-            raise NotImplementedError("discriminator_hidden_dim must be a multiple of 32, at most 256 (larger: compute_dtype = 'bf16')")
+        elif H not in (32, 64, 128, 256):
+            raise NotImplementedError("discriminator_hidden_dim must be 32, 64, 128 or 256 - the widths the layer kernels are "
+                                      "instantiated for (larger: compute_dtype = 'bf16')")
         self.feature_encoder = nn.Sequential(SNLinear(9, H), nn.LeakyReLU(0.2), SNLinear(H, H), nn.LeakyReLU(0.2))
         self.lstm = _LSTMParams(H, H, config.discriminator_num_layers, True)
         self.output_layers = nn.Sequential(SNLinear(2 * H, H), nn.LeakyReLU(0.2), nn.Dropout(config.head_dropout),

@@ -85,10 +85,42 @@ def test_condition_encoder_forward_backward_vs_float64(H, latent, B, unit_major)
         close(p.grad, q.grad, 5e-5, f'grad {k}')
 
 
-def test_condition_encoder_unsupported_width_uses_torch_ops():
+def test_widths_without_kernels_are_refused_at_construction():
+    """The persistent kernels are instantiated for H in {32, 64, 128, 256} (fp32): any other width is refused when the
+    module is built, not at its first call."""
+    import generative_mouse_trajectories_amd as gmt
+    for attr in ('generator_hidden_dim', 'discriminator_hidden_dim'):
+        cfg = gmt.Config()
+        setattr(cfg, attr, 96)
+        with pytest.raises(NotImplementedError):
+            (gmt.Generator if attr.startswith('gen') else gmt.Discriminator)(cfg)
+
+
+def test_generator_rollout_through_the_condition_kernel_matches_the_torch_composite():
+    """Generator.forward + backward with the condition encoder in csrc/mlp.hip against the same module with that switch off
+    (torch Linear / LayerNorm / LeakyReLU + F.linear + transpose): same rollout kernels either way."""
     from generative_mouse_trajectories_amd import ops
-    gmt, cfg, G = make_generator(96, 64, 1)
-    assert not ops.cond_encoder_supported(G)
+    gmt, cfg, G = make_generator(64, 16, 7)
+    G = G.to(DEV).train()
+    gen = torch.Generator().manual_seed(8)
+    B, T = 40, 9
+    start, end = torch.rand(B, 2, generator=gen).to(DEV), torch.rand(B, 2, generator=gen).to(DEV)
+    z = torch.randn(B, 16, generator=gen).to(DEV)
+    tgt = (0.01 * torch.randn(B, T, 3, generator=gen)).abs().to(DEV)
+    w = torch.randn(B, T, 3, generator=gen).to(DEV)
+    out = {}
+    for on in (True, False):
+        ops.MLP_COND = on
+        try:
+            G.zero_grad()
+            seq, _ = G(start, end, z, target_sequences=tgt, tf_mask=[False] * T)
+            (seq * w).sum().backward()
+            out[on] = (seq.detach().clone(), {k: p.grad.detach().clone() for k, p in G.named_parameters()})
+        finally:
+            ops.MLP_COND = True
+    close(out[True][0], out[False][0], 2e-5, 'rollout')
+    for k in out[False][1]:
+        close(out[True][1][k], out[False][1][k], 1e-4, f'grad {k}')
 
 
 def head_reference(x, w1, b1, w2, b2, w3, b3, slope, mask):

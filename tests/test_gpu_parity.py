@@ -368,3 +368,4 @@ def test_overlapped_generator_forward_is_the_same_step(hid, gp_every):
     assert tr1._spec_real is not None
     tr1.train_discriminator_step(other)
     assert tr1._spec_real is None
+
