@@ -127,6 +127,11 @@ def wgrad_tn(dA: torch.Tensor, X: torch.Tensor, label: Optional[str] = None) -> 
     M, N = dA.shape
     I = X.shape[1]
     assert dA.dtype == BF16 and X.dtype == BF16 and dA.stride(1) == 1 and X.stride(1) == 1 and X.shape[0] == M
+    if LIBRARY_PLAIN_GEMM and N >= 4096 and I >= 1024:
+        # the one weight-gradient shape of config 3 on which the library's fp32-output GEMM beats the kernel (layer 1's dW_ih,
+        # N = 8H, I = 2H: 932 -> 1 089 TF/s; N2048 I512 704 vs 517 and N4096 I512 879 vs 817 stay here; tools/bench_bf16_wgrad_vs_lib.py)
+        with L_.timed(label or f'bf16_wgrad_N{N}_I{I}', flops=2.0 * M * N * I):
+            return torch.mm(dA.t(), X, out_dtype=torch.float32)
     tiles = (N // 256) * (I // 256)
     n_slabs = max(1, min(64, (768 + tiles - 1) // tiles, M // 4096 if M >= 4096 else 1))
     slabs = torch.empty(n_slabs, N, I, device=dA.device, dtype=torch.float32)
