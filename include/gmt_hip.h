@@ -306,8 +306,11 @@ int gmt_lstm16_layer_bwd2(const float* pre, const float* w_hh, const int* length
 /* ---- weight-gradient contraction over time -------------------------------------------------
  * dW[n][i] (+)= sum_r dA[r][n] * X[r][i],  db[n] (+)= sum_r dA[r][n]  over R = L*B row-steps: the
  * dW_ih / dW_hh / db GEMMs autograd runs for RG.py:1021, 1109.  Split-K fp32-MFMA kernel with a
- * deterministic slab reduction.  N % 256 == 0, I % 128 == 0, R % 32 == 0; lda / ldx = row
- * pitches in floats (multiples of 4); db may be NULL; accumulate != 0 adds to dW / db.
+ * deterministic slab reduction.  N % 4 == 0 (256-wide tiles when N % 256 == 0, else 128-wide with the
+ * columns beyond N read as zero); I % 128 == 0, or I <= 32 (skinny X, any row pitch), or - round 3 - any
+ * I > 32 whose rows are readable and ZERO up to the next multiple of 128 columns (ldx >= that multiple:
+ * the saved activations of the dense-stack kernels); R % 16 == 0; lda / ldx = row pitches in floats (lda
+ * and, for the wide tiles, ldx multiples of 4); db may be NULL; accumulate != 0 adds to dW / db.
  * gmt_wgrad_workspace_floats tells the caller how large `workspace` must be.
  * x_dropout_p > 0 (I % 128 == 0 only): X is read through the dropout mask of gmt_lstm_layer_fwd,
  * element (r, i) with counter r*ldx + i. */
