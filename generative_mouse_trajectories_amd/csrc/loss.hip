@@ -31,7 +31,22 @@ void traj_from_seq_kernel(const float* __restrict__ seq, long long sb, long long
     p2[b] = make_float2(sx, sy);
     dts[b] = first_dt;
     const float* s = seq + (size_t)b * sb;
-    for (int t = 0; t < T; ++t) {
+    // one thread walks a whole trajectory: the loads do not depend on the running sums, so eight steps' worth are
+    // requested at once (the sums stay sequential: same bits) - the loop was one memory latency per step, 80-120 us
+    constexpr int U = 8;
+    int t = 0;
+    for (; t + U <= T; t += U) {
+        float vx[U], vy[U], vt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { vx[u] = s[(size_t)(t + u) * st]; vy[u] = s[(size_t)(t + u) * st + 1]; vt[u] = s[(size_t)(t + u) * st + 2]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cx += (double)vx[u]; cy += (double)vy[u];
+            p2[(size_t)(t + u + 1) * B + b] = make_float2(sx + (float)cx, sy + (float)cy);
+            dts[(size_t)(t + u + 1) * B + b] = vt[u];
+        }
+    }
+    for (; t < T; ++t) {
         const float dx = s[(size_t)t * st], dy = s[(size_t)t * st + 1], dt = s[(size_t)t * st + 2];
         cx += (double)dx; cy += (double)dy;
         p2[(size_t)(t + 1) * B + b] = make_float2(sx + (float)cx, sy + (float)cy);
@@ -50,7 +65,21 @@ void traj_from_seq_bwd_kernel(const float* __restrict__ gpos, const float* __res
     float* o = gseq + (size_t)b * sb;
     float ax = 0.f, ay = 0.f;
     const bool live = b < n_valid;
-    for (int t = T - 1; t >= 0; --t) {
+    constexpr int U = 8;
+    int t = T - 1;
+    for (; t - U + 1 >= 0; t -= U) {                     // eight steps' loads in flight, sums in the same order
+        float2 g[U]; float gd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { g[u] = g2[(size_t)(t - u + 1) * B + b]; gd[u] = gdts[(size_t)(t - u + 1) * B + b]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ax += g[u].x; ay += g[u].y;
+            o[(size_t)(t - u) * st] = live ? ax : 0.f;
+            o[(size_t)(t - u) * st + 1] = live ? ay : 0.f;
+            o[(size_t)(t - u) * st + 2] = live ? gd[u] : 0.f;
+        }
+    }
+    for (; t >= 0; --t) {
         const float2 g = g2[(size_t)(t + 1) * B + b];
         ax += g.x; ay += g.y;
         o[(size_t)t * st] = live ? ax : 0.f;
@@ -106,7 +135,21 @@ void gen_loss_fwd_kernel(const float* __restrict__ seq, long long sb, long long 
         const float* s = seq + (size_t)b * sb;
         double cx = 0.0, cy = 0.0;
         float dsum = 0.f;
-        for (int t = 0; t < len; ++t) {
+        constexpr int U = 8;
+        int t = 0;
+        for (; t + U <= len; t += U) {                   // (loads of eight steps in flight; sums in step order)
+            float vx[U], vy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { vx[u] = s[(size_t)(t + u) * st]; vy[u] = s[(size_t)(t + u) * st + 1]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float dx = vx[u], dy = vy[u];
+                cx += (double)dx; cy += (double)dy;
+                const float n = sqrtf(dx * dx + dy * dy + 1e-8f);
+                dsum += 1.0f - ((dx / n) * td.tx + (dy / n) * td.ty);
+            }
+        }
+        for (; t < len; ++t) {
             const float dx = s[(size_t)t * st], dy = s[(size_t)t * st + 1];
             cx += (double)dx; cy += (double)dy;
             const float n = sqrtf(dx * dx + dy * dy + 1e-8f);           // RG.py:1081: eps inside
@@ -171,10 +214,9 @@ void gen_loss_bwd_kernel(const float* __restrict__ seq, long long sb, long long 
         td = target_dir(starts[2 * b], starts[2 * b + 1], ends[2 * b], ends[2 * b + 1]);
     }
     const float* s = seq + (size_t)b * sb;
-    for (int t = 0; t < T; ++t) {
+    auto one = [&](int t, float dx, float dy) {
         float ox = 0.f, oy = 0.f;
         if (t < len) {
-            const float dx = s[(size_t)t * st], dy = s[(size_t)t * st + 1];
             const float n = sqrtf(dx * dx + dy * dy + 1e-8f);
             const float c = (dx / n) * td.tx + (dy / n) * td.ty;        // cosine
             // d(1 - cos)/d(dx) = -(tx / n - cos dx / n^2)
@@ -182,7 +224,17 @@ void gen_loss_bwd_kernel(const float* __restrict__ seq, long long sb, long long 
             oy = ge_y - gd * (td.ty / n - c * dy / (n * n));
         }
         o[(size_t)t * gst] = ox; o[(size_t)t * gst + 1] = oy; o[(size_t)t * gst + 2] = 0.f;
+    };
+    constexpr int U = 8;
+    int t = 0;
+    for (; t + U <= T; t += U) {                         // eight steps' loads in flight (steps are independent here)
+        float vx[U], vy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { vx[u] = s[(size_t)(t + u) * st]; vy[u] = s[(size_t)(t + u) * st + 1]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(t + u, vx[u], vy[u]);
     }
+    for (; t < T; ++t) one(t, s[(size_t)t * st], s[(size_t)t * st + 1]);
 }
 
 // The scalar arithmetic of train_generator_step after the reductions (RG.py:1069, 1072-1097), one thread:
